@@ -1,0 +1,194 @@
+# -*- coding: utf-8 -*-
+"""bench.py -- frames/sec of RMNet's per-frame inference hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1], synthetic): 480x854, 1 object (K = 2 mask channels), memory
+pinned at T = 5 frames (4 committed + the tentative previous frame).  One "step" = one frame of the
+reference's loop (models/rmnet.py:410-450, utils/helpers.py:55): TinyFlowNet on the frame pair,
+memorise frame t-1 (ResNet-50 memory encoder + KV head + region boxes + bank write), regional query
+boxes from the flow-warped previous mask, query encoder + KV head, fused regional memory read,
+decoder, soft aggregation, soft-max.  fp32 everywhere (the reference's dtype).  Inputs are resident
+in HBM before the timed region.  With N ranks every rank runs its own clip (videos are
+independent; weak scaling, no data-path collective) and ``value`` = N * K / max-over-ranks time.
+
+The JSON line also carries
+  roofline     -- the dominant hand-written kernel (mr_main, the regional memory read) timed live
+                  with HIP events recorded on its own stream around every launch of the timed
+                  region: achieved = algorithmic bytes per launch / mean duration, vs 8 TB/s HBM;
+  cpu_baseline -- the oracle's CPU restatement of the same path timed on this box's host cores
+                  (rank 0, N = 1 only; bounded sample).
+"""
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+H, W, K_CH, T_MEM = 480, 854, 2, 5
+DE, DO = 128, 512
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algorithmic_bytes(no, T, h, w):
+    """4*[(De+Do)*T*h*w + (De+Do)*h*w + 2*Do*h*w] per object-frame."""
+    hw = h * w
+    return no * 4 * ((DE + DO) * T * hw + (DE + DO) * hw + 2 * DO * hw)
+
+
+class HipEvents:
+    """Raw hipEvent_t handles (the C ABI records them on the kernel's own stream)."""
+
+    def __init__(self, n):
+        self.hip = ctypes.CDLL('libamdhip64.so')
+        self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        self.ev = []
+        for _ in range(n):
+            e = ctypes.c_void_p()
+            assert self.hip.hipEventCreate(ctypes.byref(e)) == 0
+            self.ev.append(e.value)
+
+    def elapsed_ms(self, a, b):
+        ms = ctypes.c_float()
+        rc = self.hip.hipEventElapsedTime(ctypes.byref(ms), ctypes.c_void_p(a), ctypes.c_void_p(b))
+        assert rc == 0, rc
+        return float(ms.value)
+
+
+def cpu_baseline(n_frames=5):
+    """Oracle CPU path (plain torch + C ops) on a bounded sample: one 480x854 clip, 1 object,
+    memorize_every = 1 so the memory grows 1..n_frames (mean T = 3 for 5 frames -- slightly cheaper
+    than the pinned T = 5, i.e. generous to the CPU)."""
+    from oracle import oracle
+    from rmnet_amd import networks
+    from rmnet_amd.synthetic import synthetic_clip
+    from rmnet_amd.tiny_flownet import TinyFlowNet
+    torch.set_grad_enabled(False)
+    net = networks.procedural_init_(oracle.OracleRMNet(reader='torch')).eval()
+    tfn = networks.procedural_init_(TinyFlowNet(None)).eval()
+    frames, masks, _, n_objects = synthetic_clip(n_frames + 1, K_CH, H, W, seed=0)
+    warm = frames[:, :2]
+    net(warm, masks[:, :2], tfn(warm), n_objects[:, :2], 1)            # warm-up (1 frame)
+    t0 = time.perf_counter()
+    flows = tfn(frames)
+    net(frames, masks, flows, n_objects, 1)
+    dt = time.perf_counter() - t0
+    return {'value': round(n_frames / dt, 4), 'unit': 'frames/s', 'cores': torch.get_num_threads(),
+            'kind': 'port',
+            'sample': '%d frames of one 480x854 clip, 1 object, memorize_every=1 (T=1..%d), TinyFlowNet '
+                      'included, fp32, torch %d threads; %.1f s' % (n_frames, n_frames, torch.get_num_threads(), dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True')
+    args = ap.parse_args()
+
+    from rmnet_amd import dist as rd
+    from rmnet_amd import networks
+    from rmnet_amd.rmnet import RMNet
+    from rmnet_amd.synthetic import synthetic_clip
+    from rmnet_amd.tiny_flownet import TinyFlowNet
+
+    rank, world, local = rd.init_from_env()
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    torch.set_grad_enabled(False)
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+
+    net = networks.procedural_init_(RMNet(None)).to(dev).eval()
+    tfn = networks.procedural_init_(TinyFlowNet(None)).to(dev).eval()
+    n_clip = 12
+    frames, masks, _, _ = synthetic_clip(n_clip, K_CH, H, W, seed=rank)      # every rank its own clip
+    frames, masks = frames.to(dev), masks.to(dev).float()
+
+    ctx = net._ClipContext(net, 1, K_CH, H, W, [K_CH - 1], dev)
+    bank = net.new_bank(ctx, T_MEM)
+    for t in range(1, T_MEM):                                             # fill 4 committed frames
+        flow = tfn._forward(frames[:, t], frames[:, t - 1])
+        net.frame_step(ctx, bank, frames[:, t - 1], masks[:, t - 1], frames[:, t], flow, commit=True)
+    assert bank.committed == T_MEM - 1
+
+    events = HipEvents(3 * args.steps)
+
+    def step(i, ev=None):
+        # frames cycle through the clip; the mask fed back is the synthetic blob of frame t-1 (with
+        # random-init weights the prediction itself is meaningless and would drive the boxes to
+        # degenerate sizes); all of the step's work, incl. the final soft-max, is still done.
+        t = T_MEM + (i % (n_clip - T_MEM))
+        net._profile_events = ev
+        flow = tfn._forward(frames[:, t], frames[:, t - 1])
+        logit = net.frame_step(ctx, bank, frames[:, t - 1], masks[:, t - 1], frames[:, t], flow, commit=False)
+        return torch.softmax(logit, dim=1)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    rd.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i, tuple(events.ev[3 * i:3 * i + 3]))
+    torch.cuda.synchronize()
+    rd.barrier()
+    torch.cuda.synchronize()
+    elapsed = rd.max_over_ranks(time.perf_counter() - t0)
+    assert bool(torch.isfinite(out).all())
+    net._profile_events = None
+
+    main_ms = [events.elapsed_ms(events.ev[3 * i], events.ev[3 * i + 1]) for i in range(args.steps)]
+    comb_ms = [events.elapsed_ms(events.ev[3 * i + 1], events.ev[3 * i + 2]) for i in range(args.steps)]
+    main_avg = sum(main_ms) / len(main_ms)
+    abytes = algorithmic_bytes(1, T_MEM, ctx.h, ctx.w)
+    achieved = abytes / (main_avg * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'mr_main_hbm_traffic.json')   # from a separate --pmc pass
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
+
+    if rank == 0:
+        line = {
+            'metric': 'frames/sec at 480p, 1 object, T=5 memory; memory-read HBM GB/s vs peak',
+            'value': round(world * args.steps / elapsed, 3), 'unit': 'frames/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: 480x854 synthetic clip, 1 object (K=2), memory pinned '
+                                   'at T=5, TinyFlowNet + memorize + regional read + decoder per frame',
+                       'weights': 'procedural random-init (no checkpoint offline)',
+                       'prev_mask': 'synthetic blob mask of frame t-1', 'sharding': 'one clip per rank',
+                       'miopen_find': bool(args.miopen_find)},
+            'roofline': {'bound': 'hbm', 'kernel': 'mr_main<regional> (fused regional memory read)',
+                         'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                         'algorithmic_bytes_per_launch': abytes, 'launches': args.steps,
+                         'avg_us': round(main_avg * 1e3, 2), 'min_us': round(min(main_ms) * 1e3, 2),
+                         'combine_avg_us': round(sum(comb_ms) / len(comb_ms) * 1e3, 2),
+                         'timing': 'hipEventRecord on the launch stream around every mr_main of the timed region'},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as tdist
+        tdist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

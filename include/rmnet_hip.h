@@ -1,0 +1,143 @@
+/*
+ * rmnet_hip.h -- C ABI of librmnet_hip.so: RMNet's per-frame hot path on MI355X (gfx950).
+ *
+ * This is the drop-in boundary.  Every entry point replaces one native
+ * interface (or one torch-op sequence) of the reference, hzxie/RMNet; paths below are relative
+ * to the reference checkout.  Conventions for all calls:
+ *   - plain pointers + sizes; all tensor pointers are DEVICE pointers unless the name ends in
+ *     _host; tensors are dense row-major fp32 / int32 in the reference's own layouts;
+ *   - the caller owns every buffer (inputs, outputs, workspace); nothing is allocated inside;
+ *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = the default stream);
+ *     no host synchronisation, so calls can be captured in a hipGraph;
+ *   - return value: RMNET_OK (0) or a negative RMNET_E_* code -- errors are returned, never
+ *     printed-and-ignored (the reference prints launch errors and carries on,
+ *     extensions/reg_att_map_generator/reg_att_map_generator.cu:117-121);
+ *   - re-entrant: no global mutable state, safe from one host thread per GPU
+ *     (utils/eval_server.py:249-255 calls the op that way).
+ */
+#ifndef RMNET_HIP_H_
+#define RMNET_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RMNET_ABI_VERSION 1
+
+enum {
+  RMNET_OK = 0,
+  RMNET_E_INVALID_ARG = -1, /* null pointer, non-positive size, unsupported combination */
+  RMNET_E_WORKSPACE = -2,   /* workspace pointer null or too small                        */
+  RMNET_E_LAUNCH = -3,      /* hipGetLastError() after a launch / memcpy was not success   */
+  RMNET_E_UNSUPPORTED = -4  /* shape outside what the kernels implement (see each call)    */
+};
+
+int rmnet_abi_version(void);
+const char *rmnet_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * G1/G2  Regional attention map generator.
+ * Replaces: pybind `reg_att_map_generator.forward(mask, prob_threshold, n_pts_threshold,
+ *           n_bbox_loose_pixels)` -- extensions/reg_att_map_generator/reg_att_map_generator_cuda.cpp:26-38
+ *           and its kernel, reg_att_map_generator.cu:15-123.
+ *   mask     [B,K,H,W] f32 (soft masks; channel 0 = background, never inspected)
+ *   att_map  [B,K,H,W] f32 out: 1 inside the loosened box of channel k>=1, else 0; channel 0 all 0.
+ *            May be NULL: the full-resolution map is then not written (the fused regional read
+ *            below only needs the boxes).
+ *   bboxes   [B,K,4] int32 out: (x_min, x_max, y_min, y_max); channel 0 = (0,0,0,0).
+ *   cell_rects [B,K,4] int32 out, may be NULL: the box expressed on the 1/`cell_stride` feature
+ *            grid as (cx0, cx1, cy0, cy1) inclusive -- exactly the cells that survive
+ *            F.interpolate(att_map padded by (pad_l, pad_t), scale_factor=1/cell_stride)
+ *            (models/rmnet.py:245, 307, 356); empty boxes and channel 0 give (1,0,1,0).
+ *            cells_h x cells_w is the feature-grid size.
+ * Outputs are fully written (no pre-zeroing needed).  Integer outputs are bit-exact.
+ * ------------------------------------------------------------------------------------------- */
+size_t rmnet_region_map_workspace_bytes(int B, int K, int H, int W);
+int rmnet_region_map_f32(const float *mask, int B, int K, int H, int W, float prob_threshold,
+                         int n_pts_threshold, int n_bbox_loose_pixels, float *att_map,
+                         int32_t *bboxes, int32_t *cell_rects, int pad_l, int pad_t,
+                         int cell_stride, int cells_h, int cells_w, void *workspace,
+                         size_t workspace_bytes, void *stream);
+
+/* Box -> cell rectangle only (same formula as above), for boxes already on the device. */
+int rmnet_boxes_to_cell_rects_i32(const int32_t *bboxes, int n_boxes, int k_per_batch, int pad_l,
+                                  int pad_t, int cell_stride, int cells_h, int cells_w,
+                                  int32_t *cell_rects, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * M1 (+M2/M3 fused)  Regional memory read.
+ * Replaces: MemoryReader.forward, models/rmnet.py:147-165 (bmm, /sqrt(De), softmax over THW,
+ *           bmm, cat) and -- when rectangles are given -- the K/V box masking around it,
+ *           models/rmnet.py:244-248 (memory side) and :356-358 (query side).
+ *   m_key  [no, De, T, h, w]   element (o,c,t,y,x) at o*m_obj_stride + c*m_chan_stride + t*h*w + y*w + x
+ *   m_val  [no, Do, T, h, w]   same strides rule with v_obj_stride / v_chan_stride
+ *          (contiguous NCTHW: chan_stride = T*h*w, obj_stride = C*T*h*w; a pre-allocated memory
+ *           bank of capacity Tcap uses chan_stride = Tcap*h*w).  Pass 0 to mean "contiguous".
+ *   q_key  [no, De, h, w], q_val [no, Do, h, w]   contiguous
+ *   mem_val [no, 2*Do, h, w]  out: channels [0,Do) = read-out, [Do,2Do) = q_val (masked if regional)
+ *   p_out  [no, T*h*w, h*w] out or NULL: the softmax affinity the reference returns as `viz`
+ *          (models/rmnet.py:157,165); computed only when requested (extra pass).
+ *   mem_rects [no, T, 4] int32 or NULL; qry_rects [no, 4] int32 or NULL: cell rectangles
+ *          (cx0,cx1,cy0,cy1) inclusive.  When given, cells outside a rectangle are treated as
+ *          if K, V (memory) / q_key, q_val (query) had been multiplied by 0 there -- the inputs
+ *          may be the un-masked tensors (the multiply is fused) or already masked ones.
+ *          Both NULL = dense read (drop-in MemoryReader).
+ *   flags  RMNET_MR_* below.
+ * The fast path needs De == 128 and Do == 512 (RMNet's sizes, models/rmnet.py:185-186); other
+ * sizes run a generic (slow, still on-GPU) path that needs the p-sized workspace.
+ * Floating point: fp32 MFMA accumulate; parity with the reference is a tolerance (see tests).
+ * ------------------------------------------------------------------------------------------- */
+#define RMNET_MR_DEFAULT 0
+#define RMNET_MR_FORCE_GENERIC 1 /* use the generic path even for De=128, Do=512 (testing) */
+
+size_t rmnet_memory_read_workspace_bytes(int no, int De, int Do, int T, int h, int w, int flags);
+int rmnet_memory_read_f32(const float *m_key, const float *m_val, const float *q_key,
+                          const float *q_val, int no, int De, int Do, int T, int h, int w,
+                          long long m_chan_stride, long long m_obj_stride, long long v_chan_stride,
+                          long long v_obj_stride, float *mem_val, float *p_out,
+                          const int32_t *mem_rects, const int32_t *qry_rects, int flags,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+/* Same call, with optional HIP events recorded on `stream` around the two kernels of the fast
+ * path: ev_start before mr_main, ev_mid between mr_main and mr_combine, ev_end after mr_combine
+ * (each a hipEvent_t as void*, any may be NULL).  bench.py uses this to time the dominant kernel
+ * on the stream it actually runs on; it changes nothing else. */
+int rmnet_memory_read_f32_ev(const float *m_key, const float *m_val, const float *q_key,
+                             const float *q_val, int no, int De, int Do, int T, int h, int w,
+                             long long m_chan_stride, long long m_obj_stride,
+                             long long v_chan_stride, long long v_obj_stride, float *mem_val,
+                             float *p_out, const int32_t *mem_rects, const int32_t *qry_rects,
+                             int flags, void *workspace, size_t workspace_bytes, void *stream,
+                             void *ev_start, void *ev_mid, void *ev_end);
+
+/* M2/M3 standalone: y = x * rectangle-mask, x [n, C, T, h, w] contiguous, rects [n, T, 4].
+ * Replaces the elementwise multiplies at models/rmnet.py:247-248 and :357-358 when a caller
+ * wants the masked tensors themselves (e.g. RMNet.memorize's return values). */
+int rmnet_rect_mask_f32(const float *x, int n, int C, int T, int h, int w, const int32_t *rects,
+                        float *y, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * F1  Optical-flow update after two affine warps.
+ * Replaces: CPython `flow_affine_transformation.update_optical_flow(flow, M1, M2)` --
+ *           extensions/flow_affine_transformation/flow_affine_transformation.cpp:39-90.
+ *   flow [H,W,2] f32, m1/m2 [2,3] f32 -> out [H,W,2] f32 (integer-valued).  Bit-exact with the
+ *   reference's fp32 arithmetic (no FMA contraction, round-half-away-from-zero), including its
+ *   quirk that y1 is computed from the already-updated x1 (.cpp:72-73).
+ * _host variant: all four pointers are HOST pointers (the reference's NumPy calling convention);
+ * it stages through `workspace` (device, >= rmnet_flow_affine_workspace_bytes) and synchronises
+ * the stream before returning.
+ * ------------------------------------------------------------------------------------------- */
+int rmnet_flow_affine_f32(const float *flow, const float *m1, const float *m2, int H, int W,
+                          float *out, void *stream);
+size_t rmnet_flow_affine_workspace_bytes(int H, int W);
+int rmnet_flow_affine_f32_host(const float *flow_host, const float *m1_host, const float *m2_host,
+                               int H, int W, float *out_host, void *workspace,
+                               size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RMNET_HIP_H_ */

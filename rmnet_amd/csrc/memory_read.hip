@@ -1,0 +1,570 @@
+// memory_read.hip -- fused regional memory read for gfx950.
+//
+// Reference semantics (models/rmnet.py:147-165, with the box masking of :244-248 / :356-358):
+//     S[j,i]   = sum_c m_key[c,j] * q_key[c,i] / sqrt(De)        j in T*h*w memory cells, i in h*w query cells
+//     p[:,i]   = softmax_j S[j,i]
+//     mem[d,i] = sum_j m_val[d,j] * p[j,i]
+//     out      = cat(mem, q_val)
+// where K,V (memory side) and q_key,q_val (query side) have been multiplied by 0/1 box maps.
+// The reference materialises p ([no, THW, HW] fp32) and streams it through HBM about six times.
+//
+// This file never writes p (unless asked for) and never touches a masked cell:
+//   * a masked MEMORY cell has key = 0 and value = 0, so S = 0 and it adds exp(0 - m) to the
+//     soft-max denominator and nothing to the numerator.  All N_out such cells are folded into one
+//     closed-form term N_out * exp(-m) in the combine step;
+//   * a masked QUERY cell has q_key = 0, so every S is 0, the soft-max is uniform and its read-out is
+//     the mean of m_val over all T*h*w cells -- the same vector for every masked query.  It is
+//     produced by one zero-key "mean slot" that rides along in the last query tile.
+//   So the kernel iterates over the COMPACTED unmasked memory cells x COMPACTED unmasked query
+//   cells only; rectangles are read on the device (no host sync, graph-capturable).
+//
+// mr_main (hand-tiled for wave64 / MFMA / LDS):
+//   workgroup = 4 waves = 64 queries x one split of the compacted memory axis.
+//   wave w : owns queries [16w, 16w+16) for the affinity GEMM  S = K^T Q  (v_mfma_f32_16x16x4_f32,
+//            M = memory cell, N = query, K = channel) -- the soft-max row (over memory cells) of a
+//            query lives in 4 lanes x 8 registers, so max/sum are register ops + two shuffles;
+//            owns value channels [128w, 128w+128) for O += V P  (M = channel, N = all 64 queries,
+//            K = memory cell) -- 8x4 accumulator tiles = 128 registers.
+//   LDS    : K tile [128][32], V tile [512][32] (row strides 48 / 34 floats = conflict-free for
+//            the MFMA operand reads), P tile [32][64] exchanged between the waves, alpha[64].
+//   HBM    : each K/V row segment is read with coalesced 128-byte wave transactions directly in
+//            the reference's channel-major layout (positions contiguous) -- no transpose pass;
+//            the next tile's loads are issued before the current tile's MFMAs (register staging).
+//   soft-max: online, with a deferred running reference (the accumulators are only rescaled when
+//            a tile's max exceeds the reference by > kDefer; fp32 has the range for it), so the
+//            128-register rescale almost never runs.
+//   occupancy: 1620 query cells are only 26 tiles, so the memory axis is split (flash-decoding
+//            style) until the launch has about kTargetSlots workgroups; partial (O, m, l) go to a
+//            workspace and mr_combine merges them, adds the closed-form term, scatters the mean
+//            vector to masked cells and appends q_val (x box mask) -- the cat of :163.
+//   XCD    : workgroups that share a memory split (same K/V bytes) are mapped to the same XCD so
+//            the split is fetched from HBM once per L2.
+//
+// Algorithmic bytes per object-frame: 4*[(De+Do)*T*h*w + (De+Do)*h*w + 2*Do*h*w].
+#include "common.h"
+
+namespace rmnet {
+namespace {
+
+constexpr int kDe = 128, kDo = 512;
+constexpr int kQT = 64;          // queries per workgroup
+constexpr int kJT = 32;          // memory cells per tile
+constexpr int kKS = 48;          // K tile row stride (floats): 32 + 16 -> lane groups on disjoint banks
+constexpr int kVS = 34;          // V tile row stride: 16 rows x {0,1} -> 32 distinct banks
+constexpr int kPS = 80;          // P tile row stride
+constexpr int kMaxT = 512;
+constexpr int kMaxSplits = 64;
+constexpr int kTargetSlots = 256;  // workgroups per launch the split heuristic aims for
+constexpr float kDefer = 30.0f;
+constexpr int kThreads = 256;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct KArgs {
+  const float *mk, *mv, *qk, *qv;
+  float* out;
+  const int32_t* mem_rects;  // [no][T][4] or null
+  const int32_t* qry_rects;  // [no][4] or null
+  float* ws_o;               // [no][slots][kDo][kQT]
+  float* ws_ml;              // [no][slots][2][kQT]
+  int no, T, h, w, hw;
+  long long mk_cs, mk_os, mv_cs, mv_os;
+  int slots;                 // workgroup slots per object (grid.x of mr_main)
+  float sqrt_de;
+};
+
+struct Plan {
+  int Mq;      // unmasked query cells
+  int nqt;     // query tiles (incl. the mean slot when Mq < hw)
+  int M;       // unmasked memory cells
+  int njt;     // memory tiles
+  int nsplit;  // splits of the memory axis (0 when M == 0)
+  Rect qr;
+};
+
+// Prefix sums of per-frame rectangle areas into LDS prefix[0..T]; returns the launch plan.
+// Must be called by all threads of the block (contains barriers).
+template <bool REGIONAL>
+__device__ inline Plan make_plan(const KArgs& a, int o, int* prefix) {
+  Plan p;
+  const int tid = threadIdx.x;
+  if (REGIONAL) {
+    if (tid < RMNET_WAVE) {
+      int carry = 0;
+      for (int base = 0; base < a.T; base += RMNET_WAVE) {
+        const int t = base + tid;
+        int v = 0;
+        if (t < a.T) {
+          const int32_t* r = a.mem_rects + ((size_t)o * a.T + t) * 4;
+          Rect rc{r[0], r[1], r[2], r[3]};
+          rc.cx0 = max(rc.cx0, 0); rc.cy0 = max(rc.cy0, 0);
+          rc.cx1 = min(rc.cx1, a.w - 1); rc.cy1 = min(rc.cy1, a.h - 1);
+          v = rc.area();
+        }
+        int s = v;
+#pragma unroll
+        for (int d = 1; d < RMNET_WAVE; d <<= 1) {
+          const int u = __shfl_up(s, d);
+          if (tid >= d) s += u;
+        }
+        if (t < a.T) prefix[t + 1] = carry + s;
+        carry += __shfl(s, RMNET_WAVE - 1);
+      }
+      if (tid == 0) prefix[0] = 0;
+    }
+    __syncthreads();
+    p.M = prefix[a.T];
+    const int32_t* q = a.qry_rects + (size_t)o * 4;
+    p.qr = Rect{max(q[0], 0), min(q[1], a.w - 1), max(q[2], 0), min(q[3], a.h - 1)};
+    p.Mq = p.qr.area();
+  } else {
+    p.M = a.T * a.hw;
+    p.Mq = a.hw;
+    p.qr = Rect{0, a.w - 1, 0, a.h - 1};
+  }
+  p.nqt = (p.Mq + (p.Mq < a.hw ? 1 : 0) + kQT - 1) / kQT;
+  if (p.nqt < 1) p.nqt = 1;
+  p.njt = (p.M + kJT - 1) / kJT;
+  int ns = kTargetSlots / (p.nqt * a.no);
+  if (ns > a.slots / p.nqt) ns = a.slots / p.nqt;
+  if (ns > kMaxSplits) ns = kMaxSplits;
+  if (ns < 1) ns = 1;
+  if (ns > p.njt) ns = p.njt;  // 0 when there is nothing to read
+  p.nsplit = ns;
+  return p;
+}
+
+// Compacted memory index n -> element offset t*hw + cy*w + cx (REGIONAL) or n (dense).
+template <bool REGIONAL>
+__device__ inline int mem_index(const KArgs& a, int o, const int* prefix, int n) {
+  if (!REGIONAL) return n;
+  int lo = 0, hi = a.T;  // find t with prefix[t] <= n < prefix[t+1]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (prefix[mid] <= n) lo = mid; else hi = mid;
+  }
+  const int32_t* r = a.mem_rects + ((size_t)o * a.T + lo) * 4;
+  const int cx0 = max(r[0], 0), cx1 = min(r[1], a.w - 1), cy0 = max(r[2], 0);
+  const int rw = cx1 - cx0 + 1;
+  const int rem = n - prefix[lo];
+  const int ry = rem / rw;
+  return lo * a.hw + (cy0 + ry) * a.w + cx0 + (rem - ry * rw);
+}
+
+__device__ inline int query_cell(const Plan& p, int w, int n) {
+  const int rw = p.qr.width();
+  const int ry = n / rw;
+  return (p.qr.cy0 + ry) * w + p.qr.cx0 + (n - ry * rw);
+}
+
+// Block b of a launch lands on XCD b % 8; give each XCD a contiguous range of logical ids so that
+// workgroups sharing a memory split share an L2 (bijective for any count).
+__device__ inline int xcd_remap(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+constexpr int kLdsFloats = kDe * kKS + kDo * kVS + kJT * kPS + kQT + 4 + (kMaxT + 4);
+
+template <bool REGIONAL>
+__global__ __launch_bounds__(kThreads, 1) void mr_main(const KArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+  float* Kt = lds;
+  float* Vt = Kt + kDe * kKS;
+  float* Pt = Vt + kDo * kVS;
+  float* Al = Pt + kJT * kPS;
+  int* flags = reinterpret_cast<int*>(Al + kQT);
+  int* prefix = flags + 4;
+
+  const int tid = threadIdx.x, o = blockIdx.y;
+  const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+  if (tid < 2) flags[tid] = 0;
+  const Plan pl = make_plan<REGIONAL>(a, o, prefix);
+  const int nact = pl.nqt * pl.nsplit;
+  if ((int)blockIdx.x >= nact) return;
+  const int L = xcd_remap(blockIdx.x, nact);
+  const int s = L / pl.nqt, qt = L - s * pl.nqt;
+  const int jt0 = (int)(((long long)s * pl.njt) / pl.nsplit);
+  const int jt1 = (int)(((long long)(s + 1) * pl.njt) / pl.nsplit);
+
+  // ---- query fragment (B operand of S = K^T Q): lane (l15, g) holds Q[c = 4ks + g][query l15]
+  float qreg[kDe / 4];
+  {
+    const int qn = qt * kQT + wave * 16 + l15;
+    const bool qvalid = qn < pl.Mq;
+    const int cell = qvalid ? (REGIONAL ? query_cell(pl, a.w, qn) : qn) : 0;
+    const float* qb = a.qk + (size_t)o * kDe * a.hw + cell;
+#pragma unroll
+    for (int ks = 0; ks < kDe / 4; ++ks) qreg[ks] = qvalid ? qb[(size_t)(4 * ks + g) * a.hw] : 0.0f;
+  }
+
+  // ---- staging registers: thread (jcol, rg) carries rows rg + 8k of column jcol
+  const int jcol = tid & 31, rg = tid >> 5;
+  float kst[kDe / 8], vst[kDo / 8];
+  const float* mkb = a.mk + (size_t)o * a.mk_os + (size_t)rg * a.mk_cs;
+  const float* mvb = a.mv + (size_t)o * a.mv_os + (size_t)rg * a.mv_cs;
+  auto stage_load = [&](int jt) {
+    const int n = jt * kJT + jcol;
+    if (n < pl.M) {
+      const int jg = mem_index<REGIONAL>(a, o, prefix, n);
+#pragma unroll
+      for (int k = 0; k < kDe / 8; ++k) kst[k] = mkb[(size_t)(8 * k) * a.mk_cs + jg];
+#pragma unroll
+      for (int k = 0; k < kDo / 8; ++k) vst[k] = mvb[(size_t)(8 * k) * a.mv_cs + jg];
+    } else {
+#pragma unroll
+      for (int k = 0; k < kDe / 8; ++k) kst[k] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < kDo / 8; ++k) vst[k] = 0.0f;
+    }
+  };
+  auto stage_write = [&]() {
+#pragma unroll
+    for (int k = 0; k < kDe / 8; ++k) Kt[(rg + 8 * k) * kKS + jcol] = kst[k];
+#pragma unroll
+    for (int k = 0; k < kDo / 8; ++k) Vt[(rg + 8 * k) * kVS + jcol] = vst[k];
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) acc[dt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float mref = -INFINITY, lsum = 0.0f;
+
+  stage_load(jt0);
+  for (int jt = jt0; jt < jt1; ++jt) {
+    const int par = (jt - jt0) & 1;
+    __syncthreads();  // previous tile's LDS reads are done
+    stage_write();
+    if (tid == 0) flags[par ^ 1] = 0;
+    __syncthreads();  // tile visible
+    if (jt + 1 < jt1) stage_load(jt + 1);  // in flight under the MFMAs below
+
+    // ---- S = K^T Q for this wave's 16 queries x 32 memory cells
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < kDe / 4; ++ks) {
+      const float a0 = Kt[(4 * ks + g) * kKS + l15];
+      const float a1 = Kt[(4 * ks + g) * kKS + 16 + l15];
+      s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, qreg[ks], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, qreg[ks], s1, 0, 0, 0);
+    }
+    // lane holds S[j = 4g + r (+16)][query l15]
+    float sv[8];
+    const int nbase = jt * kJT + 4 * g;
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sv[r] = (nbase + r < pl.M) ? s0[r] / a.sqrt_de : -INFINITY;          // models/rmnet.py:156
+      sv[4 + r] = (nbase + 16 + r < pl.M) ? s1[r] / a.sqrt_de : -INFINITY;
+      tmax = fmaxf(tmax, fmaxf(sv[r], sv[4 + r]));
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const bool bump = tmax > mref + kDefer;  // first tile: mref = -inf
+    float alpha = 1.0f;
+    if (bump) {
+      alpha = __expf(mref - tmax);  // exp(-inf) = 0 on the first tile
+      mref = tmax;
+    }
+    float rs = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      sv[r] = expf(sv[r] - mref);
+      rs += sv[r];
+    }
+    rs += __shfl_xor(rs, 16);
+    rs += __shfl_xor(rs, 32);
+    lsum = lsum * alpha + rs;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      Pt[(4 * g + r) * kPS + wave * 16 + l15] = sv[r];
+      Pt[(16 + 4 * g + r) * kPS + wave * 16 + l15] = sv[4 + r];
+    }
+    if (g == 0) Al[wave * 16 + l15] = alpha;
+    if (__any(bump) && lane == 0) flags[par] = 1;
+    __syncthreads();  // P, alpha, flag visible
+
+    // ---- O += V P for this wave's 128 value channels x 64 queries
+    if (flags[par]) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const float al = Al[it * 16 + l15];
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) acc[dt][it] *= al;
+      }
+    }
+    const float* Vw = Vt + (wave * 128 + l15) * kVS + g;
+#pragma unroll
+    for (int ks = 0; ks < kJT / 4; ++ks) {
+      float bq[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) bq[it] = Pt[(4 * ks + g) * kPS + it * 16 + l15];
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        const float av = Vw[dt * 16 * kVS + 4 * ks];
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+          acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bq[it], acc[dt][it], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- partial (O, m, l) -> workspace slot L
+  float* wo = a.ws_o + ((size_t)o * a.slots + L) * (size_t)kDo * kQT;
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        wo[(size_t)(wave * 128 + dt * 16 + 4 * g + r) * kQT + it * 16 + l15] = acc[dt][it][r];
+  if (g == 0) {
+    float* wm = a.ws_ml + ((size_t)o * a.slots + L) * 2 * kQT;
+    wm[wave * 16 + l15] = mref;
+    wm[kQT + wave * 16 + l15] = lsum;
+  }
+}
+
+constexpr int kCombCh = 64;  // read-out channels (and as many q_val channels) per combine block
+
+template <bool REGIONAL>
+__global__ __launch_bounds__(kThreads) void mr_combine(const KArgs a) {
+  __shared__ float Wt[kMaxSplits][kQT];
+  __shared__ int prefix[kMaxT + 4];
+  const int tid = threadIdx.x, o = blockIdx.z;
+  const Plan pl = make_plan<REGIONAL>(a, o, prefix);
+  const int ci = tid & 63, cg = tid >> 6;
+  const int cell = blockIdx.x * kQT + ci;
+  const bool live = cell < a.hw;
+  bool inside = true;
+  int n = cell;
+  if (REGIONAL && live) {
+    const int cy = cell / a.w, cx = cell - cy * a.w;
+    inside = pl.qr.contains(cy, cx);
+    n = inside ? (cy - pl.qr.cy0) * pl.qr.width() + (cx - pl.qr.cx0) : pl.Mq;  // mean slot
+  }
+  if (!live) n = 0;
+  const int qt = n >> 6, qi = n & 63;
+  const float n_out = (float)(a.T * a.hw - pl.M);
+  const float* ml = a.ws_ml + (size_t)o * a.slots * 2 * kQT;
+  if (cg == 0) {
+    float mtot = n_out > 0.0f ? 0.0f : -INFINITY;
+    for (int s = 0; s < pl.nsplit; ++s) mtot = fmaxf(mtot, ml[((size_t)(s * pl.nqt + qt) * 2) * kQT + qi]);
+    float ltot = n_out > 0.0f ? n_out * expf(-mtot) : 0.0f;
+    for (int s = 0; s < pl.nsplit; ++s) {
+      const float* e = ml + ((size_t)(s * pl.nqt + qt) * 2) * kQT;
+      const float wgt = expf(e[qi] - mtot);
+      Wt[s][ci] = wgt;
+      ltot += e[kQT + qi] * wgt;
+    }
+    const float inv = 1.0f / ltot;
+    for (int s = 0; s < pl.nsplit; ++s) Wt[s][ci] *= inv;
+  }
+  __syncthreads();
+  if (!live) return;
+  const float* wo = a.ws_o + (size_t)o * a.slots * (size_t)kDo * kQT;
+  float* out = a.out + (size_t)o * 2 * kDo * a.hw + cell;
+  const float* qv = a.qv + (size_t)o * kDo * a.hw + cell;
+  for (int dd = cg; dd < kCombCh; dd += 4) {
+    const int d = blockIdx.y * kCombCh + dd;
+    float acc = 0.0f;
+    for (int s = 0; s < pl.nsplit; ++s)
+      acc += Wt[s][ci] * wo[((size_t)(s * pl.nqt + qt) * kDo + d) * kQT + qi];
+    out[(size_t)d * a.hw] = acc;
+    const float v = qv[(size_t)d * a.hw];
+    out[(size_t)(kDo + d) * a.hw] = inside ? v : v * 0.0f;  // cat(mem, q_val * box), :163 / :358
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Generic path (any De <= 256, any Do) and the optional p output: a plain three-pass soft-max
+// that materialises p, then a plain V p product.  Correct for every shape, not tuned: RMNet only
+// ever uses De = 128 / Do = 512 and never reads p (models/rmnet.py:361-366).
+// ------------------------------------------------------------------------------------------
+struct GArgs {
+  const float *mk, *mv, *qk, *qv;
+  float* out;
+  float* p;  // [no][THW][hw]
+  const int32_t* mem_rects;
+  const int32_t* qry_rects;
+  int no, De, Do, T, h, w, hw;
+  long long mk_cs, mk_os, mv_cs, mv_os;
+  float sqrt_de;
+};
+
+__device__ inline bool mem_live(const GArgs& a, int o, int j) {
+  if (!a.mem_rects) return true;
+  const int t = j / a.hw, pos = j - t * a.hw;
+  const int cy = pos / a.w, cx = pos - cy * a.w;
+  const int32_t* r = a.mem_rects + ((size_t)o * a.T + t) * 4;
+  return cx >= r[0] && cx <= r[1] && cy >= r[2] && cy <= r[3];
+}
+__device__ inline bool qry_live(const GArgs& a, int o, int cell) {
+  if (!a.qry_rects) return true;
+  const int cy = cell / a.w, cx = cell - cy * a.w;
+  const int32_t* r = a.qry_rects + (size_t)o * 4;
+  return cx >= r[0] && cx <= r[1] && cy >= r[2] && cy <= r[3];
+}
+
+__global__ __launch_bounds__(kThreads) void p_kernel(const GArgs a) {
+  extern __shared__ float qs[];  // [De][64] query tile, then red[4][64]
+  float* red = qs + a.De * 64;
+  const int tid = threadIdx.x, ci = tid & 63, jj = tid >> 6, o = blockIdx.y;
+  const int cell = blockIdx.x * 64 + ci;
+  const bool live = cell < a.hw;
+  const bool qin = live && qry_live(a, o, cell);
+  for (int c = jj; c < a.De; c += 4)
+    qs[c * 64 + ci] = qin ? a.qk[(size_t)o * a.De * a.hw + (size_t)c * a.hw + cell] : 0.0f;
+  __syncthreads();
+  const int thw = a.T * a.hw;
+  float* pc = a.p + (size_t)o * thw * a.hw + cell;
+  const float* mk = a.mk + (size_t)o * a.mk_os;
+  float mx = -INFINITY;
+  for (int j = jj; j < thw; j += 4) {
+    float dot = 0.0f;
+    if (mem_live(a, o, j))
+      for (int c = 0; c < a.De; ++c) dot += mk[(size_t)c * a.mk_cs + j] * qs[c * 64 + ci];
+    const float sc = dot / a.sqrt_de;
+    if (live) pc[(size_t)j * a.hw] = sc;
+    mx = fmaxf(mx, sc);
+  }
+  red[jj * 64 + ci] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[ci], red[64 + ci]), fmaxf(red[128 + ci], red[192 + ci]));
+  __syncthreads();
+  float sum = 0.0f;
+  if (live)
+    for (int j = jj; j < thw; j += 4) {
+      const float e = expf(pc[(size_t)j * a.hw] - mx);
+      pc[(size_t)j * a.hw] = e;
+      sum += e;
+    }
+  red[jj * 64 + ci] = sum;
+  __syncthreads();
+  sum = red[ci] + red[64 + ci] + red[128 + ci] + red[192 + ci];
+  if (live)
+    for (int j = jj; j < thw; j += 4) pc[(size_t)j * a.hw] = pc[(size_t)j * a.hw] / sum;
+}
+
+__global__ __launch_bounds__(kThreads) void pv_kernel(const GArgs a) {
+  const int tid = threadIdx.x, ci = tid & 63, dg = tid >> 6, o = blockIdx.z;
+  const int cell = blockIdx.x * 64 + ci;
+  if (cell >= a.hw) return;
+  const int thw = a.T * a.hw;
+  const int d0 = (blockIdx.y * 4 + dg) * 4;
+  const float* pc = a.p + (size_t)o * thw * a.hw + cell;
+  const float* mv = a.mv + (size_t)o * a.mv_os;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < thw; ++j) {
+    if (!mem_live(a, o, j)) continue;
+    const float pj = pc[(size_t)j * a.hw];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (d0 + u < a.Do) acc[u] += mv[(size_t)(d0 + u) * a.mv_cs + j] * pj;
+  }
+  const bool qin = qry_live(a, o, cell);
+  float* out = a.out + (size_t)o * 2 * a.Do * a.hw + cell;
+  const float* qv = a.qv + (size_t)o * a.Do * a.hw + cell;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (d0 + u < a.Do) {
+      out[(size_t)(d0 + u) * a.hw] = acc[u];
+      const float v = qv[(size_t)(d0 + u) * a.hw];
+      out[(size_t)(a.Do + d0 + u) * a.hw] = qin ? v : v * 0.0f;
+    }
+}
+
+inline bool fast_shape(int De, int Do, int T, int flags) {
+  return De == kDe && Do == kDo && T <= kMaxT && !(flags & RMNET_MR_FORCE_GENERIC);
+}
+
+inline int slots_for(int no, int hw) {
+  const int nqt_max = (hw + 1 + kQT - 1) / kQT;
+  const int per_obj = (kTargetSlots + no - 1) / no;
+  return nqt_max > per_obj ? nqt_max : per_obj;
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+size_t memory_read_ws_bytes(int no, int De, int Do, int T, int h, int w, int flags) {
+  const size_t hw = (size_t)h * w;
+  if (fast_shape(De, Do, T, flags)) {
+    const size_t slots = slots_for(no, (int)hw);
+    return align256((size_t)no * slots * kDo * kQT * 4) + align256((size_t)no * slots * 2 * kQT * 4);
+  }
+  return align256((size_t)no * T * hw * hw * 4);  // a p-sized buffer
+}
+
+int launch_memory_read(const MemReadArgs& m, hipStream_t st) {
+  if (!m.mk || !m.mv || !m.qk || !m.qv || !m.out) return RMNET_E_INVALID_ARG;
+  if (m.no <= 0 || m.De <= 0 || m.Do <= 0 || m.T <= 0 || m.h <= 0 || m.w <= 0)
+    return RMNET_E_INVALID_ARG;
+  if ((m.mem_rects == nullptr) != (m.qry_rects == nullptr)) return RMNET_E_INVALID_ARG;
+  const long long hw = (long long)m.h * m.w, thw = hw * m.T;
+  if (thw > (1LL << 30) || m.no > 65535) return RMNET_E_UNSUPPORTED;
+  const long long mk_cs = m.mk_cs ? m.mk_cs : thw, mv_cs = m.mv_cs ? m.mv_cs : thw;
+  const long long mk_os = m.mk_os ? m.mk_os : mk_cs * m.De, mv_os = m.mv_os ? m.mv_os : mv_cs * m.Do;
+  if (mk_cs < thw || mv_cs < thw) return RMNET_E_INVALID_ARG;
+  const bool regional = m.mem_rects != nullptr;
+  const bool fast = fast_shape(m.De, m.Do, m.T, m.flags);
+  const float sqrt_de = sqrtf((float)m.De);
+
+  if (fast) {
+    if (!m.ws || m.ws_bytes < memory_read_ws_bytes(m.no, m.De, m.Do, m.T, m.h, m.w, m.flags))
+      return RMNET_E_WORKSPACE;
+    KArgs a;
+    a.mk = m.mk; a.mv = m.mv; a.qk = m.qk; a.qv = m.qv; a.out = m.out;
+    a.mem_rects = m.mem_rects; a.qry_rects = m.qry_rects;
+    a.no = m.no; a.T = m.T; a.h = m.h; a.w = m.w; a.hw = (int)hw;
+    a.mk_cs = mk_cs; a.mk_os = mk_os; a.mv_cs = mv_cs; a.mv_os = mv_os;
+    a.slots = slots_for(m.no, (int)hw);
+    a.sqrt_de = sqrt_de;
+    a.ws_o = static_cast<float*>(m.ws);
+    a.ws_ml = reinterpret_cast<float*>(static_cast<char*>(m.ws) +
+                                       align256((size_t)m.no * a.slots * kDo * kQT * 4));
+    dim3 g1(a.slots, m.no), g2((unsigned)((hw + kQT - 1) / kQT), kDo / kCombCh, m.no);
+    if (m.ev_start && hipEventRecord(m.ev_start, st) != hipSuccess) return RMNET_E_LAUNCH;
+    if (regional)
+      hipLaunchKernelGGL(mr_main<true>, g1, dim3(kThreads), 0, st, a);
+    else
+      hipLaunchKernelGGL(mr_main<false>, g1, dim3(kThreads), 0, st, a);
+    if (int e = check_launch()) return e;
+    if (m.ev_mid && hipEventRecord(m.ev_mid, st) != hipSuccess) return RMNET_E_LAUNCH;
+    if (regional)
+      hipLaunchKernelGGL(mr_combine<true>, g2, dim3(kThreads), 0, st, a);
+    else
+      hipLaunchKernelGGL(mr_combine<false>, g2, dim3(kThreads), 0, st, a);
+    if (int e = check_launch()) return e;
+    if (m.ev_end && hipEventRecord(m.ev_end, st) != hipSuccess) return RMNET_E_LAUNCH;
+    if (!m.p_out) return RMNET_OK;
+  }
+
+  // generic path and/or the p output
+  if (m.De > 224) return RMNET_E_UNSUPPORTED;  // query tile must fit 64 KB of dynamic LDS
+  GArgs ga;
+  ga.mk = m.mk; ga.mv = m.mv; ga.qk = m.qk; ga.qv = m.qv; ga.out = m.out;
+  ga.mem_rects = m.mem_rects; ga.qry_rects = m.qry_rects;
+  ga.no = m.no; ga.De = m.De; ga.Do = m.Do; ga.T = m.T; ga.h = m.h; ga.w = m.w; ga.hw = (int)hw;
+  ga.mk_cs = mk_cs; ga.mk_os = mk_os; ga.mv_cs = mv_cs; ga.mv_os = mv_os;
+  ga.sqrt_de = sqrt_de;
+  ga.p = m.p_out;
+  if (!ga.p) {
+    if (!m.ws || m.ws_bytes < align256((size_t)m.no * thw * hw * 4)) return RMNET_E_WORKSPACE;
+    ga.p = static_cast<float*>(m.ws);
+  }
+  const size_t shm = ((size_t)m.De * 64 + 256) * sizeof(float);
+  hipLaunchKernelGGL(p_kernel, dim3((unsigned)((hw + 63) / 64), m.no), dim3(kThreads), shm, st, ga);
+  if (int e = check_launch()) return e;
+  if (!fast) {
+    hipLaunchKernelGGL(pv_kernel, dim3((unsigned)((hw + 63) / 64), (m.Do + 15) / 16, m.no),
+                       dim3(kThreads), 0, st, ga);
+    if (int e = check_launch()) return e;
+  }
+  return RMNET_OK;
+}
+
+}  // namespace rmnet

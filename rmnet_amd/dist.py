@@ -1,0 +1,127 @@
+# -*- coding: utf-8 -*-
+"""Per-video data parallelism over the GPUs of one node.
+
+Clips are independent (frame t needs the mask of frame t-1, but clips share nothing --
+models/rmnet.py:410-450), so the path shards across videos: one process per GPU, video v goes to a
+rank chosen by a longest-first greedy balance of its cost N*n_objects, weights are replicated and
+there is NO communication while a clip runs.  The only collective is the gather of the per-video
+outputs (uint8 label maps) at the end: a flat gather to rank 0, which on MI355X uses each peer's
+direct xGMI link (the backend is "nccl" = RCCL on ROCm; "gloo" on CPU for the tests).
+
+The reference has no counterpart: its DataParallel wrapper runs batch size 1 on one GPU
+(core/inference.py:23-37) and utils/eval_server.py:78-87 shards checkpoints, not videos.
+"""
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from torchrun's environment (RANK / WORLD_SIZE / LOCAL_RANK /
+    MASTER_ADDR / MASTER_PORT).  Returns (rank, world_size, local_rank).  A single process without
+    those variables is rank 0 of 1 and no process group is created."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, world, local
+
+
+def assign_videos(costs, world_size):
+    """Longest-first greedy assignment.  ``costs[v]`` ~ N_frames * n_objects of video v.
+    Returns a list ``owner[v]`` of ranks; deterministic, identical on every rank."""
+    order = sorted(range(len(costs)), key=lambda v: (-costs[v], v))
+    load = [0] * world_size
+    owner = [0] * len(costs)
+    for v in order:
+        r = min(range(world_size), key=lambda i: (load[i], i))
+        owner[v] = r
+        load[r] += costs[v]
+    return owner
+
+
+def my_videos(costs, rank, world_size):
+    return [v for v, r in enumerate(assign_videos(costs, world_size)) if r == rank]
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value, device=None):
+    """MAX all-reduce of a Python float (used for the step timing of bench.py)."""
+    if not dist.is_initialized():
+        return float(value)
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' \
+            else torch.device('cpu')
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device=None):
+    if not dist.is_initialized():
+        return float(value)
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' \
+            else torch.device('cpu')
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def gather_label_maps(results, n_videos, dst=0):
+    """Gather per-video label maps on rank ``dst``.
+
+    ``results``: dict video_id -> uint8 tensor [N,H,W] (this rank's videos; on the rank's device for
+    nccl, CPU for gloo).  Two phases: (1) all_gather of a fixed-size int64 header table
+    [n_videos, 4] = (owner_has_it, N, H, W); (2) one all_gather of the ranks' payloads padded to the
+    largest rank payload (flat uint8) -- RCCL has no variable-size gather, padding costs at most one
+    extra clip per rank over xGMI.  Returns {video_id: tensor} on ``dst`` and {} elsewhere."""
+    if not dist.is_initialized():
+        return dict(results)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    on_gpu = dist.get_backend() == 'nccl'
+    dev = torch.device('cuda', torch.cuda.current_device()) if on_gpu else torch.device('cpu')
+    header = torch.zeros(n_videos, 4, dtype=torch.int64, device=dev)
+    for v, t in results.items():
+        header[v] = torch.tensor([1, t.shape[0], t.shape[1], t.shape[2]], dtype=torch.int64, device=dev)
+    headers = [torch.zeros_like(header) for _ in range(world)]
+    dist.all_gather(headers, header)
+    sizes = [int((h[:, 0] * h[:, 1] * h[:, 2] * h[:, 3]).sum()) for h in headers]
+    cap = max(max(sizes), 1)
+    payload = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    at = 0
+    for v in sorted(results):
+        flat = results[v].to(dev).reshape(-1)
+        payload[at:at + flat.numel()] = flat
+        at += flat.numel()
+    payloads = [torch.zeros_like(payload) for _ in range(world)]
+    dist.all_gather(payloads, payload)
+    out = {}
+    if rank == dst:
+        for r in range(world):
+            at = 0
+            h = headers[r]
+            for v in range(n_videos):
+                if int(h[v, 0]):
+                    n, hh, ww = int(h[v, 1]), int(h[v, 2]), int(h[v, 3])
+                    out[v] = payloads[r][at:at + n * hh * ww].reshape(n, hh, ww).clone()
+                    at += n * hh * ww
+    return out

@@ -1,0 +1,234 @@
+# -*- coding: utf-8 -*-
+"""Convolutional sub-networks of RMNet, kept on stock PyTorch-ROCm (MIOpen).
+
+SURVEY.md section 8 row C1: these stacks are *not* part of the hand-written hot path; they
+are declared here only so that (a) the host-side mirror in ``rmnet_amd.rmnet`` has something
+to feed the HIP kernels with and (b) public RMNet checkpoints load unchanged.  Every module
+and parameter name below therefore matches the reference's state-dict keys:
+
+    reference                                       here
+    models/rmnet.py:24-48   ResBlock                ResBlock        (downsample/conv1/conv2)
+    models/rmnet.py:51-80   EncoderMemory           EncoderMemory   (conv1_m/conv1_o/conv1/bn1/res2-4)
+    models/rmnet.py:83-104  EncoderQuery            EncoderQuery    (conv1/bn1/res2-4)
+    models/rmnet.py:107-120 Refine                  Refine          (convFS/ResFS/ResMM)
+    models/rmnet.py:123-140 Decoder                 Decoder         (convFM/ResMM/RF3/RF2/pred2)
+    models/rmnet.py:168-176 KeyValue                KeyValue        (key_conv/value_conv)
+
+The reference takes its trunk from ``torchvision.models.resnet50`` (models/rmnet.py:57,86);
+torchvision is not available in this image, so the ResNet-50 stem and stages 1-3 are declared
+here with torchvision's parameter names (``conv1/bn1/conv2/bn2/conv3/bn3/downsample.{0,1}``),
+stride on the 3x3 convolution (the "v1.5" variant torchvision ships).
+"""
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+class _Bottleneck(nn.Module):
+    """ResNet-50 bottleneck: 1x1 reduce, 3x3 (carries the stride), 1x1 expand (x4)."""
+
+    def __init__(self, c_in, width, stride, project):
+        super().__init__()
+        c_out = width * 4
+        self.conv1 = nn.Conv2d(c_in, width, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = nn.Conv2d(width, width, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = nn.Conv2d(width, c_out, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(c_out)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if project:
+            self.downsample = nn.Sequential(nn.Conv2d(c_in, c_out, 1, stride=stride, bias=False),
+                                            nn.BatchNorm2d(c_out))
+
+    def forward(self, x):
+        skip = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        return self.relu(y + skip)
+
+
+def _stage(c_in, width, n_blocks, stride):
+    blocks = [_Bottleneck(c_in, width, stride, project=True)]
+    blocks += [_Bottleneck(width * 4, width, 1, project=False) for _ in range(n_blocks - 1)]
+    return nn.Sequential(*blocks)
+
+
+class ResNet50Trunk(nn.Module):
+    """Stem + layer1..layer3 of ResNet-50 with torchvision attribute names."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        self.layer1 = _stage(64, 64, 3, 1)      # 1/4,  256 ch
+        self.layer2 = _stage(256, 128, 4, 2)    # 1/8,  512 ch
+        self.layer3 = _stage(512, 256, 6, 2)    # 1/16, 1024 ch
+
+
+def resnet50(pretrained=False):
+    """Stand-in for ``torchvision.models.resnet50``; ``pretrained`` is ignored (no network)."""
+    return ResNet50Trunk()
+
+
+class ResBlock(nn.Module):
+    """Pre-activation two-conv residual block (models/rmnet.py:24-48)."""
+
+    def __init__(self, indim, outdim=None, stride=1):
+        super().__init__()
+        outdim = indim if outdim is None else outdim
+        self.downsample = None
+        if not (indim == outdim and stride == 1):
+            self.downsample = nn.Conv2d(indim, outdim, 3, padding=1, stride=stride)
+        self.conv1 = nn.Conv2d(indim, outdim, 3, padding=1, stride=stride)
+        self.conv2 = nn.Conv2d(outdim, outdim, 3, padding=1)
+
+    def forward(self, x):
+        r = self.conv2(F.relu(self.conv1(F.relu(x))))
+        return (x if self.downsample is None else self.downsample(x)) + r
+
+
+class EncoderMemory(nn.Module):
+    """Frame + object mask + other-objects mask -> r4 (models/rmnet.py:51-80)."""
+
+    def __init__(self, trunk_factory=resnet50):
+        super().__init__()
+        self.conv1_m = nn.Conv2d(1, 64, 7, stride=2, padding=3, bias=False)
+        self.conv1_o = nn.Conv2d(1, 64, 7, stride=2, padding=3, bias=False)
+        trunk = trunk_factory(pretrained=True)
+        self.conv1, self.bn1, self.relu, self.maxpool = trunk.conv1, trunk.bn1, trunk.relu, trunk.maxpool
+        self.res2, self.res3, self.res4 = trunk.layer1, trunk.layer2, trunk.layer3
+
+    def forward(self, in_f, in_m, in_o):
+        m = in_m.unsqueeze(1).float()
+        o = in_o.unsqueeze(1).float()
+        c1 = self.relu(self.bn1(self.conv1(in_f) + self.conv1_m(m) + self.conv1_o(o)))
+        r2 = self.res2(self.maxpool(c1))
+        r3 = self.res3(r2)
+        r4 = self.res4(r3)
+        return r4, r3, r2, c1, in_f
+
+
+class EncoderQuery(nn.Module):
+    """Frame -> (r4, r3, r2) (models/rmnet.py:83-104)."""
+
+    def __init__(self, trunk_factory=resnet50):
+        super().__init__()
+        trunk = trunk_factory(pretrained=True)
+        self.conv1, self.bn1, self.relu, self.maxpool = trunk.conv1, trunk.bn1, trunk.relu, trunk.maxpool
+        self.res2, self.res3, self.res4 = trunk.layer1, trunk.layer2, trunk.layer3
+
+    def forward(self, in_f):
+        c1 = self.relu(self.bn1(self.conv1(in_f)))
+        r2 = self.res2(self.maxpool(c1))
+        r3 = self.res3(r2)
+        r4 = self.res4(r3)
+        return r4, r3, r2, c1, in_f
+
+
+class Refine(nn.Module):
+    """Skip-feature fusion + x2 bilinear upsample of the coarser map (models/rmnet.py:107-120)."""
+
+    def __init__(self, inplanes, planes, scale_factor=2):
+        super().__init__()
+        self.convFS = nn.Conv2d(inplanes, planes, 3, padding=1)
+        self.ResFS = ResBlock(planes, planes)
+        self.ResMM = ResBlock(planes, planes)
+        self.scale_factor = scale_factor
+
+    def forward(self, f, pm):
+        s = self.ResFS(self.convFS(f))
+        up = F.interpolate(pm, scale_factor=self.scale_factor, mode='bilinear', align_corners=False)
+        return self.ResMM(s + up)
+
+
+class Decoder(nn.Module):
+    """[mem | q_val] (1024 ch) + r3 + r2 -> 2-class logits at full resolution
+    (models/rmnet.py:123-140)."""
+
+    def __init__(self, mdim):
+        super().__init__()
+        self.convFM = nn.Conv2d(1024, mdim, 3, padding=1)
+        self.ResMM = ResBlock(mdim, mdim)
+        self.RF3 = Refine(512, mdim)
+        self.RF2 = Refine(256, mdim)
+        self.pred2 = nn.Conv2d(mdim, 2, 3, padding=1)
+
+    def forward(self, r4, r3, r2):
+        m4 = self.ResMM(self.convFM(r4))
+        m3 = self.RF3(r3, m4)
+        m2 = self.RF2(r2, m3)
+        p2 = self.pred2(F.relu(m2))
+        return F.interpolate(p2, scale_factor=4, mode='bilinear', align_corners=False)
+
+
+class KeyValue(nn.Module):
+    """Two 3x3 heads on r4 (models/rmnet.py:168-176)."""
+
+    def __init__(self, indim, keydim, valdim):
+        super().__init__()
+        self.key_conv = nn.Conv2d(indim, keydim, 3, padding=1)
+        self.value_conv = nn.Conv2d(indim, valdim, 3, padding=1)
+
+    def forward(self, x):
+        return self.key_conv(x), self.value_conv(x)
+
+
+def _hash_uniform(n, seed):
+    """Exact integer hash (murmur3 finaliser on idx*2654435761 + seed) -> float64 in [-1, 1).
+    Pure int64 tensor arithmetic: bit-identical on every torch version / platform."""
+    m32 = 0xFFFFFFFF
+    x = (torch.arange(n, dtype=torch.int64) * 2654435761 + seed * 40503 + 0x9E3779B9) & m32
+    x = x ^ (x >> 16)
+    x = (x * 0x85EBCA6B) & m32
+    x = x ^ (x >> 13)
+    x = (x * 0xC2B2AE35) & m32
+    x = x ^ (x >> 16)
+    return x.to(torch.float64) * (2.0 / 4294967296.0) - 1.0
+
+
+def procedural_init_(module, gain=0.9):
+    """Deterministic, RNG-free weight fill used for fixtures and benchmarks (no checkpoint is
+    reachable offline).  Every tensor is filled from an integer hash of (flat index, state-dict
+    key); convolution weights get He scaling x ``gain``, the last conv of every residual branch
+    is damped so activations stay O(1) through ResNet-50 with identity BatchNorm statistics."""
+    import math
+    with torch.no_grad():
+        for name, t in module.state_dict().items():
+            if name.endswith('num_batches_tracked'):
+                continue
+            seed = sum((i + 1) * ord(ch) for i, ch in enumerate(name)) % 1000003
+            n = t.numel()
+            noise = _hash_uniform(n, seed)
+            if name.endswith('running_var'):
+                val = torch.ones(n, dtype=torch.float64)
+            elif name.endswith('running_mean'):
+                val = torch.zeros(n, dtype=torch.float64)
+            elif t.dim() == 1 and name.endswith('weight'):      # BN gamma
+                val = 1.0 + 0.05 * noise
+            elif name.endswith('bias'):
+                val = 0.05 * noise
+            elif t.dim() == 4:
+                fan_in = t.shape[1] * t.shape[2] * t.shape[3]
+                if module_is_transposed(module, name):
+                    fan_in = t.shape[0] * t.shape[2] * t.shape[3] // 4
+                std = gain * math.sqrt(2.0 / max(fan_in, 1))
+                if name.endswith('conv3.weight') or name.endswith('conv2.weight') and '.Res' in name:
+                    std *= 0.5          # residual-branch output: keep the running sum from doubling
+                val = noise * (std * math.sqrt(3.0))
+            else:
+                val = 0.05 * noise
+            t.copy_(val.reshape(t.shape).to(t.dtype))
+    return module
+
+
+def module_is_transposed(module, key):
+    mod = module
+    for part in key.split('.')[:-1]:
+        mod = getattr(mod, part) if not part.isdigit() else mod[int(part)]
+    return isinstance(mod, nn.ConvTranspose2d)

@@ -1,0 +1,181 @@
+# -*- coding: utf-8 -*-
+"""Torch-facing wrappers over the C ABI.  PyTorch is plumbing here (device memory, current stream,
+current device); all arithmetic happens in librmnet_hip.so.
+
+Input validation mirrors the reference's pybind layer
+(extensions/reg_att_map_generator/reg_att_map_generator_cuda.cpp:14-19: CUDA + contiguous, else
+RuntimeError) and additionally checks dtype, which the reference only assumes.
+"""
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _check(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise RuntimeError('%s must be a torch.Tensor' % name)
+    if not t.is_cuda:
+        raise RuntimeError('%s must be a CUDA tensor' % name)      # CHECK_CUDA
+    if not t.is_contiguous():
+        raise RuntimeError('%s must be contiguous' % name)          # CHECK_CONTIGUOUS
+    if t.dtype != dtype:
+        raise RuntimeError('%s must be %s, got %s' % (name, dtype, t.dtype))
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _ws(nbytes, dev):
+    # the caching allocator makes this a pointer bump; stream-ordered like any torch temporary
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+
+
+def region_map(mask, prob_threshold=0.5, n_pts_threshold=10, n_bbox_loose_pixels=64,
+               want_map=True, cell_grid=None):
+    """mask [B,K,H,W] f32 cuda -> (att_map [B,K,H,W] f32 | None, bboxes [B,K,4] i32, rects | None).
+
+    ``cell_grid = (pad_l, pad_t, stride, cells_h, cells_w)`` additionally returns the boxes as cell
+    rectangles on the 1/stride feature grid (see include/rmnet_hip.h)."""
+    _check(mask, 'mask')
+    if mask.dim() != 4:
+        raise RuntimeError('mask must be [B, K, H, W]')
+    lib = _lib.load()
+    B, K, H, W = mask.shape
+    dev = mask.device
+    with torch.cuda.device(dev):
+        att = torch.empty_like(mask) if want_map else None
+        bboxes = torch.empty(B, K, 4, dtype=torch.int32, device=dev)
+        rects = torch.empty(B, K, 4, dtype=torch.int32, device=dev) if cell_grid is not None else None
+        pl, pt, st, ch, cw = cell_grid if cell_grid is not None else (0, 0, 16, 1, 1)
+        nb = lib.rmnet_region_map_workspace_bytes(B, K, H, W)
+        ws = _ws(nb, dev)
+        rc = lib.rmnet_region_map_f32(_ptr(mask), B, K, H, W, float(prob_threshold),
+                                      int(n_pts_threshold), int(n_bbox_loose_pixels), _ptr(att),
+                                      _ptr(bboxes), _ptr(rects), int(pl), int(pt), int(st), int(ch),
+                                      int(cw), _ptr(ws), ws.numel(), _stream(dev))
+    _lib.check(rc, 'rmnet_region_map_f32')
+    return att, bboxes, rects
+
+
+def boxes_to_cell_rects(bboxes, pad_l, pad_t, stride, cells_h, cells_w, k_per_batch=0):
+    """bboxes [..., 4] i32 cuda -> cell rectangles, same shape.  ``k_per_batch`` > 0 marks every
+    k-th box (channel 0) as empty."""
+    _check(bboxes, 'bboxes', torch.int32)
+    lib = _lib.load()
+    dev = bboxes.device
+    out = torch.empty_like(bboxes)
+    with torch.cuda.device(dev):
+        rc = lib.rmnet_boxes_to_cell_rects_i32(_ptr(bboxes), bboxes.numel() // 4, int(k_per_batch),
+                                               int(pad_l), int(pad_t), int(stride), int(cells_h),
+                                               int(cells_w), _ptr(out), _stream(dev))
+    _lib.check(rc, 'rmnet_boxes_to_cell_rects_i32')
+    return out
+
+
+def memory_read(m_key, m_val, q_key, q_val, mem_rects=None, qry_rects=None, want_p=False, flags=0,
+                T=None, out=None, events=None):
+    """Fused (regional) memory read.
+
+    m_key [no,De,Tcap,h,w], m_val [no,Do,Tcap,h,w] (only the first ``T`` frames are read; default
+    all), q_key [no,De,h,w], q_val [no,Do,h,w]; optional mem_rects [no,T,4] / qry_rects [no,4] i32.
+    ``events`` = (ev_start, ev_mid, ev_end) raw hipEvent_t handles (ints) recorded around the two
+    kernels of the fast path (profiling only).
+    Returns (mem_val [no,2*Do,h,w], p [no,T*h*w,h*w] | None)."""
+    for t, n in ((m_key, 'm_key'), (m_val, 'm_val'), (q_key, 'q_key'), (q_val, 'q_val')):
+        _check(t, n)
+    if m_key.dim() != 5 or m_val.dim() != 5 or q_key.dim() != 4 or q_val.dim() != 4:
+        raise RuntimeError('expected m_key/m_val [no,C,T,h,w] and q_key/q_val [no,C,h,w]')
+    no, De, Tcap, h, w = m_key.shape
+    Do = m_val.shape[1]
+    if (m_val.shape[0], m_val.shape[2], m_val.shape[3], m_val.shape[4]) != (no, Tcap, h, w) or \
+            tuple(q_key.shape) != (no, De, h, w) or tuple(q_val.shape) != (no, Do, h, w):
+        raise RuntimeError('memory/query shapes do not agree')
+    T = Tcap if T is None else int(T)
+    if not 1 <= T <= Tcap:
+        raise RuntimeError('T must be in [1, %d]' % Tcap)
+    if (mem_rects is None) != (qry_rects is None):
+        raise RuntimeError('mem_rects and qry_rects must be given together')
+    if mem_rects is not None:
+        _check(mem_rects, 'mem_rects', torch.int32)
+        _check(qry_rects, 'qry_rects', torch.int32)
+        if mem_rects.numel() != no * T * 4 or qry_rects.numel() != no * 4:
+            raise RuntimeError('mem_rects must be [no,T,4] and qry_rects [no,4]')
+    lib = _lib.load()
+    dev = m_key.device
+    with torch.cuda.device(dev):
+        if out is None:
+            out = torch.empty(no, 2 * Do, h, w, dtype=torch.float32, device=dev)
+        else:
+            _check(out, 'out')
+        p = torch.empty(no, T * h * w, h * w, dtype=torch.float32, device=dev) if want_p else None
+        nb = lib.rmnet_memory_read_workspace_bytes(no, De, Do, T, h, w, int(flags))
+        ws = _ws(nb, dev)
+        cs = Tcap * h * w
+        ev = [ctypes.c_void_p(e) if e else None for e in (events or (None, None, None))]
+        rc = lib.rmnet_memory_read_f32_ev(_ptr(m_key), _ptr(m_val), _ptr(q_key), _ptr(q_val), no, De, Do,
+                                          T, h, w, cs, cs * De, cs, cs * Do, _ptr(out), _ptr(p),
+                                          _ptr(mem_rects), _ptr(qry_rects), int(flags), _ptr(ws),
+                                          ws.numel(), _stream(dev), ev[0], ev[1], ev[2])
+    _lib.check(rc, 'rmnet_memory_read_f32')
+    return out, p
+
+
+def rect_mask(x, rects):
+    """x [n,C,T,h,w] * 0/1 cell rectangles [n,T,4] (models/rmnet.py:247-248, 357-358)."""
+    _check(x, 'x')
+    _check(rects, 'rects', torch.int32)
+    n, C, T, h, w = x.shape
+    if rects.numel() != n * T * 4:
+        raise RuntimeError('rects must be [n,T,4]')
+    lib = _lib.load()
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = lib.rmnet_rect_mask_f32(_ptr(x), n, C, T, h, w, _ptr(rects), _ptr(y), _stream(x.device))
+    _lib.check(rc, 'rmnet_rect_mask_f32')
+    return y
+
+
+def flow_affine(flow, m1, m2):
+    """Device-resident variant: flow [H,W,2] f32 cuda, m1/m2 [2,3] f32 cuda -> [H,W,2]."""
+    for t, n in ((flow, 'flow'), (m1, 'm1'), (m2, 'm2')):
+        _check(t, n)
+    if flow.dim() != 3 or flow.shape[2] != 2 or m1.numel() != 6 or m2.numel() != 6:
+        raise RuntimeError('expected flow [H,W,2] and 2x3 matrices')
+    lib = _lib.load()
+    out = torch.empty_like(flow)
+    with torch.cuda.device(flow.device):
+        rc = lib.rmnet_flow_affine_f32(_ptr(flow), _ptr(m1), _ptr(m2), flow.shape[0], flow.shape[1],
+                                       _ptr(out), _stream(flow.device))
+    _lib.check(rc, 'rmnet_flow_affine_f32')
+    return out
+
+
+def update_optical_flow(optical_flow, tr_matrix1, tr_matrix2, device=None):
+    """NumPy calling convention of the reference's CPython module
+    (flow_affine_transformation.cpp:87-90): ndarray in, new ndarray out -- computed on the GPU.
+    Unlike the reference (which reinterprets whatever buffer it is given, .cpp:50-52) the inputs
+    are checked/converted to C-contiguous float32."""
+    flow = np.ascontiguousarray(optical_flow, dtype=np.float32)
+    m1 = np.ascontiguousarray(tr_matrix1, dtype=np.float32)
+    m2 = np.ascontiguousarray(tr_matrix2, dtype=np.float32)
+    if flow.ndim != 3 or flow.shape[2] != 2 or m1.size != 6 or m2.size != 6:
+        raise RuntimeError('expected flow [H,W,2] and 2x3 matrices')
+    lib = _lib.load()
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    H, W = flow.shape[:2]
+    out = np.empty_like(flow)
+    with torch.cuda.device(dev):
+        ws = _ws(lib.rmnet_flow_affine_workspace_bytes(H, W), dev)
+        rc = lib.rmnet_flow_affine_f32_host(flow.ctypes.data, m1.ctypes.data, m2.ctypes.data, H, W,
+                                            out.ctypes.data, _ptr(ws), ws.numel(), _stream(dev))
+    _lib.check(rc, 'rmnet_flow_affine_f32_host')
+    return out

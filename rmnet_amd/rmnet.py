@@ -1,0 +1,307 @@
+# -*- coding: utf-8 -*-
+"""Host-side mirror of the reference's ``models/rmnet.py`` on top of the gfx950 kernels.
+
+Same classes, constructor arguments, method names, argument meaning and state-dict keys as the
+reference (``RMNet``, ``MemoryReader``, ``KeyValue``, ``Decoder`` ...; models/rmnet.py:123-452), so
+``rmnet.load_state_dict(checkpoint['rmnet'])`` and
+``rmnet(frames, masks, optical_flows, n_objects, memorize_every)`` work unchanged.  What differs is
+how the per-frame loop is carried out:
+
+=====================================  ==========================================================
+reference (models/rmnet.py)            here
+=====================================  ==========================================================
+full-res 0/1 box maps, x1/16 nearest,  the region kernel emits the box AND its cell rectangle;
+4 elementwise multiplies (:244-248,    the full-resolution map is not written and K/V are never
+:356-358)                              multiplied -- the read kernel skips masked cells exactly
+bmm / div / softmax / bmm / cat with   one fused regional read (csrc/memory_read.hip), p never
+p materialised (:147-165)              materialised
+K-slot zero padding + torch.cat of     pre-allocated per-object bank [no, C, Tcap, h, w]; memorising
+the whole memory every frame           = one strided slab write; the tentative "previous frame"
+(:191-205, :416-426)                   slot is simply overwritten until it is committed
+est_masks on the host, H2D/D2H and     clip resident on the device, no host sync inside the frame
+.item()/.tolist() every frame          loop (object bookkeeping is hoisted to clip start)
+(:386-402, :412-413, :436-450)
+=====================================  ==========================================================
+
+There is no CPU fallback: every call goes through librmnet_hip.so (rmnet_amd._lib) or raises.
+"""
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+from .helpers import pad_amounts, pad_divide_by
+from .networks import Decoder, EncoderMemory, EncoderQuery, KeyValue, Refine, ResBlock  # noqa: F401
+from .reg_att_map_generator import RegionalAttentionMapGenerator
+
+_ABSENT_LOGIT = -16.1181          # models/rmnet.py:441, 448
+_NEW_OBJECT_SCALE = 32.0605       # models/rmnet.py:441
+
+
+class MemoryReader(nn.Module):
+    """models/rmnet.py:143-165.  ``forward(m_key, m_val, q_key, q_val) -> (mem_val, p)``.
+
+    ``p`` (the [no, THW, HW] affinity the reference returns as ``viz`` and never uses, :361-366) is
+    only computed when ``return_affinity=True``; otherwise the second element is ``None``.
+    Optional ``mem_rects`` / ``qry_rects`` select the fused regional form."""
+
+    def __init__(self, return_affinity=False):
+        super().__init__()
+        self.return_affinity = return_affinity
+
+    def forward(self, m_key, m_val, q_key, q_val, mem_rects=None, qry_rects=None, T=None):
+        return ops.memory_read(m_key.contiguous(), m_val.contiguous(), q_key.contiguous(),
+                               q_val.contiguous(), mem_rects, qry_rects,
+                               want_p=self.return_affinity, T=T)
+
+
+class _MemoryBank:
+    """Append-only per-object key/value memory in the kernel's layout (replaces the torch.cat at
+    models/rmnet.py:416-426 and the K-slot padding of :191-205)."""
+
+    def __init__(self, no, keydim, valdim, capacity, h, w, device):
+        self.keys = torch.zeros(no, keydim, capacity, h, w, device=device)
+        self.values = torch.zeros(no, valdim, capacity, h, w, device=device)
+        self.boxes = torch.zeros(no, capacity, 4, dtype=torch.int32, device=device)
+        self.rects = torch.zeros(no, capacity, 4, dtype=torch.int32, device=device)
+        self.committed = 0
+        self.capacity = capacity
+
+    def stage(self, k4, v4, boxes, rects):
+        """Write one frame into the first free slot without committing it."""
+        s = self.committed
+        if s >= self.capacity:
+            raise RuntimeError('memory bank overflow (%d slots)' % self.capacity)
+        self.keys[:, :, s] = k4
+        self.values[:, :, s] = v4
+        self.boxes[:, s] = boxes
+        self.rects[:, s] = rects
+        return s + 1          # frames visible to the read
+
+    def commit(self):
+        self.committed += 1
+
+
+class RMNet(nn.Module):
+    def __init__(self, cfg=None):
+        super().__init__()
+        self.cfg = cfg
+        self.encoder_memory = EncoderMemory()
+        self.encoder_query = EncoderQuery()
+        self.kv_memory = KeyValue(1024, keydim=128, valdim=512)
+        self.kv_query = KeyValue(1024, keydim=128, valdim=512)
+        self.memory = MemoryReader()
+        self.decoder = Decoder(256)
+        self.att_map_generator = RegionalAttentionMapGenerator()
+        self._grid_cache = {}
+
+    # ------------------------------------------------------------------ checkpoint convenience
+    def load_reference_state_dict(self, state_dict, strict=True):
+        """Accepts the reference's checkpoints with or without DataParallel's ``module.`` prefix
+        (core/inference.py:43, utils/eval_server.py:92)."""
+        clean = {(k[7:] if k.startswith('module.') else k): v for k, v in state_dict.items()}
+        return self.load_state_dict(clean, strict=strict)
+
+    # ------------------------------------------------------------------ small helpers
+    @staticmethod
+    def _object_index(n_objects, K, device):
+        """Flat indices b*K + o of the objects in flight (o = 1..n_objects[b]) and their batch ids."""
+        flat = [b * K + o for b, n in enumerate(n_objects) for o in range(1, n + 1)]
+        batch = [b for b, n in enumerate(n_objects) for _ in range(n)]
+        return (torch.tensor(flat, dtype=torch.long, device=device),
+                torch.tensor(batch, dtype=torch.long, device=device))
+
+    def _base_grid(self, B, H, W, device):
+        key = (B, H, W, str(device))
+        g = self._grid_cache.get(key)
+        if g is None:
+            xs = torch.arange(W, dtype=torch.float32, device=device).view(1, 1, 1, W).expand(B, 1, H, W)
+            ys = torch.arange(H, dtype=torch.float32, device=device).view(1, 1, H, 1).expand(B, 1, H, W)
+            g = torch.cat((xs, ys), dim=1).contiguous()
+            self._grid_cache = {key: g}
+        return g
+
+    # ------------------------------------------------------------------ reference API: pieces
+    def pad_memory(self, mems, n_objects, K):
+        """models/rmnet.py:191-205 -- kept for API parity (the frame loop below does not use it)."""
+        out = []
+        B = len(n_objects)
+        for mem in mems:
+            _, C, H, W = mem.shape
+            padded = mem.new_zeros(B, K, C, 1, H, W)
+            at = 0
+            for b in range(B):
+                padded[b, 1:n_objects[b] + 1, :, 0] = mem[at:at + n_objects[b]]
+                at += n_objects[b]
+            out.append(padded)
+        return out
+
+    def warp(self, img0, flow):
+        """models/rmnet.py:252-278: bilinear backward warp + validity mask (PyTorch-ROCm ops)."""
+        B, C, H, W = img0.shape
+        vgrid = self._base_grid(B, H, W, img0.device) + flow
+        gx = 2.0 * vgrid[:, 0] / max(W - 1, 1) - 1.0
+        gy = 2.0 * vgrid[:, 1] / max(H - 1, 1) - 1.0
+        grid = torch.stack((gx, gy), dim=3)
+        img1 = F.grid_sample(img0, grid, align_corners=True)
+        mask = F.grid_sample(torch.ones_like(img0), grid, align_corners=True)
+        mask = (mask >= 0.9999).to(img0.dtype)
+        return img1 * mask, mask
+
+    def get_att_map(self, prev_mask, flow=None):
+        """models/rmnet.py:280-287 -> (att_map [B,K,H,W], bbox [B,K,4])."""
+        expt = prev_mask if flow is None else self.warp(prev_mask, flow)[0]
+        return self.att_map_generator(expt.contiguous())
+
+    def _encode_memory(self, frame, masks, n_objects):
+        """EncoderMemory + KeyValue for every object in flight, and the boxes of the (padded)
+        masks as pixel boxes + cell rectangles.  K/V are returned UN-masked."""
+        B, K, H, W = masks.shape
+        (frame, masks), _ = pad_divide_by([frame, masks.float()], 16, (H, W))
+        fs, ms, os_ = [], [], []
+        for b in range(B):
+            n = n_objects[b]
+            for o in range(1, n + 1):
+                fs.append(frame[b:b + 1])
+                ms.append(masks[b, o:o + 1])
+                if n == 1:
+                    os_.append(torch.zeros_like(masks[b, o:o + 1]))
+                else:  # same summation order as models/rmnet.py:224-226
+                    others = masks[b, 1:o].sum(0, keepdim=True) + masks[b, o + 1:n + 1].sum(0, keepdim=True)
+                    os_.append(others.clamp(0, 1))
+        r4 = self.encoder_memory(torch.cat(fs), torch.cat(ms), torch.cat(os_))[0]
+        k4, v4 = self.kv_memory(r4)
+        h, w = k4.shape[-2:]
+        _, bboxes, rects = ops.region_map(masks.contiguous(), want_map=False, cell_grid=(0, 0, 16, h, w))
+        return k4, v4, bboxes, rects
+
+    def memorize(self, frame, masks, n_objects):
+        """models/rmnet.py:207-250 with the reference's return values:
+        (k4 [B,K,128,1,h,w], v4 [B,K,512,1,h,w], bboxes [B,K,4]), K/V box-masked."""
+        B, K = masks.shape[:2]
+        k4, v4, bboxes, rects = self._encode_memory(frame, masks, n_objects)
+        k4, v4 = self.pad_memory([k4, v4], n_objects, K)
+        r = rects.view(B * K, 1, 4)
+        k4 = ops.rect_mask(k4.view(B * K, -1, 1, *k4.shape[-2:]).contiguous(), r).view_as(k4)
+        v4 = ops.rect_mask(v4.view(B * K, -1, 1, *v4.shape[-2:]).contiguous(), r).view_as(v4)
+        return k4, v4, bboxes
+
+    def soft_aggregation(self, ps, K, n_objects):
+        """models/rmnet.py:289-302."""
+        B = len(n_objects)
+        em = ps.new_zeros(B, K, *ps.shape[1:])
+        at = 0
+        for b in range(B):
+            sl = ps[at:at + n_objects[b]]
+            em[b, 0] = torch.prod(1 - sl, dim=0)
+            em[b, 1:n_objects[b] + 1] = sl
+            at += n_objects[b]
+        em = torch.clamp(em, 1e-7, 1 - 1e-7)
+        return torch.log(em / (1 - em))
+
+    def _segment_core(self, frame, qry_rects, m_key, m_val, mem_rects, T, n_objects, K, batch_of_obj):
+        """Everything of ``segment`` after the box bookkeeping: query encoder, fused regional read,
+        decoder, soft aggregation, un-pad."""
+        (frame,), pad = pad_divide_by([frame], 16, frame.shape[2:])
+        r4, r3, r2, _, _ = self.encoder_query(frame)
+        k4, v4 = self.kv_query(r4)
+        if frame.shape[0] == 1 and len(batch_of_obj) == 1:
+            k4e, v4e, r3e, r2e = k4, v4, r3, r2
+        else:
+            k4e, v4e = k4.index_select(0, batch_of_obj), v4.index_select(0, batch_of_obj)
+            r3e, r2e = r3.index_select(0, batch_of_obj), r2.index_select(0, batch_of_obj)
+        m4, _ = ops.memory_read(m_key, m_val, k4e.contiguous(), v4e.contiguous(), mem_rects, qry_rects, T=T,
+                                events=getattr(self, '_profile_events', None))
+        ps = F.softmax(self.decoder(m4, r3e, r2e), dim=1)[:, 1]
+        logit = self.soft_aggregation(ps, K, n_objects)
+        lw, uw, lh, uh = pad
+        return logit[:, :, lh:logit.shape[2] - uh, lw:logit.shape[3] - uw]
+
+    def segment(self, frame, att_map, keys, values, prev_bboxes, curr_bbox, n_objects):
+        """models/rmnet.py:304-383, same arguments.  ``att_map`` is implied by ``curr_bbox`` (it is
+        the box map of those boxes) and the memory masking by ``prev_bboxes`` [B,K,T,4]; keys/values
+        [B,K,C,T,h,w] may be masked (as ``memorize`` returns them) or not."""
+        B, K, _, T, h, w = keys.shape
+        H, W = frame.shape[2:]
+        lw, _, lh, _ = pad_amounts(H, W, 16)
+        flat, batch_of_obj = self._object_index(n_objects, K, frame.device)
+        m_key = keys.reshape(B * K, -1, T, h, w).index_select(0, flat).contiguous()
+        m_val = values.reshape(B * K, -1, T, h, w).index_select(0, flat).contiguous()
+        # memory boxes are in padded-frame coordinates (memorize pads first), query boxes are not
+        mem_rects = ops.boxes_to_cell_rects(
+            prev_bboxes.reshape(B * K, T, 4).index_select(0, flat).contiguous().int(), 0, 0, 16, h, w)
+        qry_rects = ops.boxes_to_cell_rects(
+            curr_bbox.reshape(B * K, 4).index_select(0, flat).contiguous().int(), lw, lh, 16, h, w)
+        return self._segment_core(frame, qry_rects, m_key, m_val, mem_rects, T, n_objects, K, batch_of_obj)
+
+    # ------------------------------------------------------------------ reference API: the loop
+    class _ClipContext:
+        """Per-clip constants of the frame loop (object bookkeeping hoisted out of the loop)."""
+
+        def __init__(self, net, B, K, H, W, n_max, device):
+            self.B, self.K, self.H, self.W, self.n_max = B, K, H, W, list(n_max)
+            self.flat, self.batch_of_obj = net._object_index(self.n_max, K, device)
+            lw, uw, lh, uh = pad_amounts(H, W, 16)
+            self.lw, self.lh = lw, lh
+            self.h, self.w = (H + lh + uh) // 16, (W + lw + uw) // 16
+            self.device = device
+
+    def new_bank(self, ctx, capacity):
+        return _MemoryBank(len(ctx.flat), self.kv_memory.key_conv.out_channels,
+                           self.kv_memory.value_conv.out_channels, capacity, ctx.h, ctx.w, ctx.device)
+
+    def frame_step(self, ctx, bank, prev_frame, prev_mask, cur_frame, cur_flow, commit):
+        """One iteration of models/rmnet.py:410-433: memorise frame t-1 (tentatively, or for good
+        when ``commit``), derive the regional query boxes from the flow-warped previous mask, segment
+        frame t.  Returns the logits [B,K,H,W].  No host synchronisation."""
+        B, K = ctx.B, ctx.K
+        k4, v4, boxes, rects = self._encode_memory(prev_frame, prev_mask, ctx.n_max)
+        T = bank.stage(k4, v4, boxes.view(B * K, 4).index_select(0, ctx.flat),
+                       rects.view(B * K, 4).index_select(0, ctx.flat))
+        if commit:
+            bank.commit()
+        expt = self.warp(prev_mask, cur_flow)[0]            # models/rmnet.py:429-431
+        _, _, q_rects = ops.region_map(expt.contiguous(), want_map=False,
+                                       cell_grid=(ctx.lw, ctx.lh, 16, ctx.h, ctx.w))
+        q_rects = q_rects.view(B * K, 4).index_select(0, ctx.flat)
+        return self._segment_core(cur_frame, q_rects, bank.keys, bank.values,
+                                  bank.rects[:, :T].contiguous(), T, ctx.n_max, K, ctx.batch_of_obj)
+
+    def forward(self, frames, masks, optical_flows, n_objects, memorize_every, device=None):
+        """models/rmnet.py:385-452.  frames [B,N,3,H,W] f32, masks [B,N,K,H,W] (one-hot, any int or
+        float dtype), optical_flows [B,N,2,H,W] f32, n_objects [B,N] int -> est_masks [B,N,K,H,W]
+        f32 on the GPU (the reference returns them on the host unless several GPUs are visible)."""
+        dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        frames = frames.to(dev, non_blocking=True)
+        optical_flows = optical_flows.to(dev, non_blocking=True)
+        masks_dev = masks.to(dev, non_blocking=True)
+        B, N, _, H, W = frames.shape
+        K = masks.shape[2]
+        est = torch.zeros(B, N, K, H, W, device=dev)
+        est[:, 0] = masks_dev[:, 0]
+
+        # ---- clip-level bookkeeping, hoisted out of the frame loop (the only host syncs)
+        n_obj_host = n_objects.cpu()
+        n_max = [int(n_obj_host[b].max()) for b in range(B)]
+        existing = [torch.unique(torch.argmax(masks_dev[b, 0], dim=0)).tolist() for b in range(B)]
+        fresh = {j for j in range(1, N) if bool((n_obj_host[:, j] != n_obj_host[:, j - 1]).any())}
+        commit = set(range(0, N, memorize_every)) | fresh
+        ctx = self._ClipContext(self, B, K, H, W, n_max, dev)
+        bank = self.new_bank(ctx, sum(1 for j in commit if j <= N - 2) + 1)
+
+        for t in range(1, N):
+            logit = self.frame_step(ctx, bank, frames[:, t - 1], est[:, t - 1], frames[:, t],
+                                    optical_flows[:, t], (t - 1) in commit)
+            if t in fresh:      # models/rmnet.py:436-441
+                for b in range(B):
+                    for j in torch.unique(torch.argmax(masks_dev[b, t], dim=0)).tolist():
+                        if j not in existing[b]:
+                            existing[b].append(j)
+                            logit[b, j] = masks_dev[b, t, j].float() * _NEW_OBJECT_SCALE + _ABSENT_LOGIT
+            for b in range(B):  # models/rmnet.py:444-448
+                missing = [j for j in range(n_max[b] + 1) if j not in existing[b]]
+                if missing:
+                    logit[b, missing] = _ABSENT_LOGIT
+            est[:, t] = F.softmax(logit, dim=1)
+        return est

@@ -1,0 +1,198 @@
+# -*- coding: utf-8 -*-
+"""Generate tests/golden/*.npz by running the REFERENCE (hzxie/RMNet at /root/reference).
+
+Runs only in the build container (the GPU box has no /root/reference).  Nothing from the
+reference is copied: the script imports its Python modules in place, feeds them seeded inputs
+and stores inputs + outputs as data.  Two imports the reference needs do not exist here and
+are pre-seeded in ``sys.modules``:
+
+* ``torchvision.models.resnet50``  -> ``rmnet_amd.networks.resnet50`` (torch-only trunk with
+  torchvision's parameter names; weights are procedural either way -- no network access);
+* the compiled CUDA module ``reg_att_map_generator`` (cannot be built: nvcc absent)
+  -> ``oracle.region_map`` on CPU.  Consequence: fixtures that pass through the region map pin
+  the *rest* of the path against the reference; the region map itself is pinned by the
+  hand-computed known-answer file ``region_map_kat.json`` (written by hand, not by this script).
+
+``flow_affine`` vectors come from the reference's own C++ compiled by oracle/Makefile
+(oracle/_ref/flow_affine_transformation.so).
+
+    python tests/golden/make_golden.py        # rewrites the .npz files next to this script
+"""
+
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+
+from oracle import oracle  # noqa: E402
+from rmnet_amd import networks  # noqa: E402
+from rmnet_amd.synthetic import synthetic_clip  # noqa: E402
+
+
+def _install_stand_ins():
+    tv = types.ModuleType('torchvision')
+    tvm = types.ModuleType('torchvision.models')
+    tvm.resnet50 = networks.resnet50
+    tv.models = tvm
+    sys.modules['torchvision'] = tv
+    sys.modules['torchvision.models'] = tvm
+
+    ext = types.ModuleType('reg_att_map_generator')
+
+    def forward(mask, prob_threshold, n_pts_threshold, n_bbox_loose_pixels):
+        att, bb = oracle.region_map(mask.detach().cpu().numpy(), prob_threshold, n_pts_threshold,
+                                    n_bbox_loose_pixels)
+        return torch.from_numpy(att), torch.from_numpy(bb)
+
+    ext.forward = forward
+    sys.modules['reg_att_map_generator'] = ext
+    sys.path.insert(0, REF)
+
+
+def _load_ref_flow_ext():
+    so = os.path.join(ROOT, 'oracle', '_ref', 'flow_affine_transformation.so')
+    spec = importlib.util.spec_from_file_location('flow_affine_transformation', so)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def main():
+    _install_stand_ins()
+    import models.rmnet as ref_rmnet          # the reference, imported in place
+    import models.tiny_flownet as ref_tfn
+    import utils.helpers as ref_helpers
+    torch.manual_seed(0)
+    torch.set_grad_enabled(False)
+    rng = np.random.RandomState(1234)
+
+    # ---------------------------------------------------------------- MemoryReader (M1)
+    reader = ref_rmnet.MemoryReader()
+    cases = {}
+
+    def mr_case(name, no, De, Do, T, h, w, zero_mem=None, zero_qry=None, keep_p=False, scale=1.0):
+        mk = (rng.randn(no, De, T, h, w) * scale).astype(np.float32)
+        mv = rng.randn(no, Do, T, h, w).astype(np.float32)
+        qk = (rng.randn(no, De, h, w) * scale).astype(np.float32)
+        qv = rng.randn(no, Do, h, w).astype(np.float32)
+        if zero_mem is not None:
+            for o in range(no):
+                for t in range(T):
+                    cx0, cx1, cy0, cy1 = zero_mem[o][t]
+                    keep = np.zeros((h, w), np.float32)
+                    keep[cy0:cy1 + 1, cx0:cx1 + 1] = 1
+                    mk[o, :, t] *= keep
+                    mv[o, :, t] *= keep
+        if zero_qry is not None:
+            for o in range(no):
+                cx0, cx1, cy0, cy1 = zero_qry[o]
+                keep = np.zeros((h, w), np.float32)
+                keep[cy0:cy1 + 1, cx0:cx1 + 1] = 1
+                qk[o] *= keep
+                qv[o] *= keep
+        out, p = reader(torch.from_numpy(mk), torch.from_numpy(mv), torch.from_numpy(qk),
+                        torch.from_numpy(qv))
+        cases[name + '.m_key'], cases[name + '.m_val'] = mk, mv
+        cases[name + '.q_key'], cases[name + '.q_val'] = qk, qv
+        cases[name + '.mem_val'] = out.numpy()
+        if zero_mem is not None:
+            cases[name + '.mem_rects'] = np.asarray(zero_mem, np.int32)
+        if zero_qry is not None:
+            cases[name + '.qry_rects'] = np.asarray(zero_qry, np.int32)
+        if keep_p:
+            cases[name + '.p'] = p.numpy()
+
+    mr_case('dense', 1, 128, 512, 2, 6, 8, scale=0.5)
+    mr_case('regional', 2, 128, 512, 2, 6, 8, scale=0.5,
+            zero_mem=[[(1, 5, 0, 3), (2, 7, 2, 5)], [(0, 7, 0, 5), (3, 3, 1, 4)]],
+            zero_qry=[(2, 6, 1, 4), (0, 4, 0, 5)])
+    mr_case('allmasked_query', 1, 128, 512, 3, 5, 7, scale=0.5,
+            zero_mem=[[(0, 6, 0, 4), (1, 4, 1, 3), (1, 0, 1, 0)]], zero_qry=[(1, 0, 1, 0)])
+    mr_case('tiny_p', 1, 16, 32, 1, 3, 4, keep_p=True)
+    mr_case('peaky', 1, 128, 512, 2, 4, 5, scale=3.0)      # large logits: exercises the running max
+    np.savez_compressed(os.path.join(HERE, 'memory_reader.npz'), **cases)
+
+    # ---------------------------------------------------------------- flow affine (F1)
+    ext = _load_ref_flow_ext()
+    fa = {}
+
+    def fa_case(name, H, W, m1, m2, amp):
+        flow = (rng.rand(H, W, 2).astype(np.float32) - 0.5) * amp
+        m1 = np.asarray(m1, np.float32).reshape(2, 3)
+        m2 = np.asarray(m2, np.float32).reshape(2, 3)
+        fa[name + '.flow'], fa[name + '.m1'], fa[name + '.m2'] = flow, m1, m2
+        fa[name + '.out'] = ext.update_optical_flow(flow, m1, m2)
+
+    ident = [1, 0, 0, 0, 1, 0]
+    th = 0.3
+    rot = [1.1 * np.cos(th), -1.1 * np.sin(th), 3.5, 1.1 * np.sin(th), 1.1 * np.cos(th), -2.25]
+    fa_case('identity', 48, 64, ident, ident, 6.0)
+    fa_case('rand01', 48, 64, rng.rand(6), rng.rand(6), 1.0)        # what the reference's test.py feeds
+    fa_case('rot_scale', 48, 64, rot, [0.9, 0.05, -1.0, -0.05, 0.9, 2.0], 10.0)
+    fa_case('out_of_range', 37, 53, rot, ident, 400.0)              # clamps on every side
+    fa_case('half_ties', 16, 24, [1, 0, 0.5, 0, 1, -0.5], [1, 0, 1.5, 0, 1, 2.5], 0.0)  # round half away
+    np.savez_compressed(os.path.join(HERE, 'flow_affine.npz'), **fa)
+
+    # ---------------------------------------------------------------- pad_divide_by (H1)
+    pads = {}
+    for (h, w, d) in [(480, 854, 16), (480, 910, 16), (720, 1280, 16), (150, 250, 16), (480, 854, 64),
+                      (33, 47, 16)]:
+        (x,), pad = ref_helpers.pad_divide_by([torch.zeros(1, 1, h, w)], d, (h, w))
+        pads['%dx%d/%d' % (h, w, d)] = {'pad': [int(v) for v in pad], 'shape': list(x.shape[2:])}
+    with open(os.path.join(HERE, 'pad_divide_by.json'), 'w') as f:
+        json.dump(pads, f, indent=1, sort_keys=True)
+
+    # ---------------------------------------------------------------- RMNet glue (P1-P5, A1)
+    net = ref_rmnet.RMNet(None)
+    networks.procedural_init_(net)
+    net.eval()
+    N, K, H, W = 4, 3, 150, 250
+    frames, masks, flows, n_objects = synthetic_clip(N, K, H, W, seed=3)
+    g = {}
+    g['state_keys'] = np.array(sorted(net.state_dict().keys()))
+    g['weights_checksum'] = np.float64(sum(float(v.double().abs().sum()) for v in net.state_dict().values()))
+    # A1: warp + region map
+    soft = torch.rand(1, K, H, W, generator=torch.Generator().manual_seed(5))
+    warped, valid = net.warp(soft, flows[:, 1] * 2.5)
+    g['warp.in'], g['warp.flow'] = soft.numpy(), (flows[:, 1] * 2.5).numpy()
+    g['warp.out'], g['warp.valid'] = warped.numpy(), valid.numpy()
+    # P1: memorize frame 0
+    k4, v4, bb = net.memorize(frames[:, 0], masks[:, 0].float(), [K - 1])
+    g['memorize.k4'], g['memorize.bboxes'] = k4.numpy(), bb.numpy()
+    g['memorize.v4_every4'] = v4[:, :, ::4].contiguous().numpy()   # keeps the fixture small
+    # P4: soft aggregation
+    ps = torch.rand(K - 1, 20, 30, generator=torch.Generator().manual_seed(6))
+    g['softagg.ps'], g['softagg.logit'] = ps.numpy(), net.soft_aggregation(ps, K, [K - 1]).numpy()
+    # P5: whole clip, memorize_every = 2 so that both the committed and the tentative slot occur
+    est = net(frames, masks, flows, n_objects, 2)
+    g['clip.N'], g['clip.K'], g['clip.H'], g['clip.W'], g['clip.seed'] = N, K, H, W, 3
+    g['clip.memorize_every'] = 2
+    g['clip.est_argmax'] = est.argmax(dim=2).numpy().astype(np.uint8)
+    g['clip.est_last_obj1'] = est[:, -1, 1].numpy()
+    g['clip.est_t1'] = est[:, 1].numpy()
+    np.savez_compressed(os.path.join(HERE, 'rmnet_clip.npz'), **g)
+
+    # ---------------------------------------------------------------- TinyFlowNet (C2)
+    tfn = ref_tfn.TinyFlowNet(None)
+    networks.procedural_init_(tfn)
+    tfn.eval()
+    small = frames[:, :2, :, :70, :100].contiguous()
+    fl = tfn(small)
+    np.savez_compressed(os.path.join(HERE, 'tiny_flownet.npz'), frames=small.numpy(), flows=fl.numpy(),
+                        state_keys=np.array(sorted(tfn.state_dict().keys())))
+    print('golden fixtures written to', HERE)
+    for fn in sorted(os.listdir(HERE)):
+        print('  %-24s %8d B' % (fn, os.path.getsize(os.path.join(HERE, fn))))
+
+
+if __name__ == '__main__':
+    main()

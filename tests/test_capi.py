@@ -1,0 +1,65 @@
+# -*- coding: utf-8 -*-
+"""The C-ABI library builds, loads on a machine without a GPU and exports every symbol that
+include/rmnet_hip.h declares (no compute calls here)."""
+
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, 'include', 'rmnet_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(rmnet_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_builds_and_exports_every_header_symbol():
+    from rmnet_amd import _lib, build
+    path = build.build_library()
+    assert os.path.exists(path)
+    lib = ctypes.CDLL(path)
+    syms = _header_symbols()
+    assert len(syms) >= 11, syms
+    for s in syms:
+        assert hasattr(lib, s), 'missing export: ' + s
+    assert sorted(_lib.SIGNATURES.keys()) == syms     # the ctypes table covers the whole header
+
+
+def test_error_strings_and_sizes_need_no_gpu():
+    from rmnet_amd import _lib
+    lib = _lib.load()
+    assert lib.rmnet_abi_version() == 1
+    assert lib.rmnet_error_string(0) == b'ok'
+    for code in (-1, -2, -3, -4):
+        assert len(lib.rmnet_error_string(code)) > 4
+    # workspace queries are pure host arithmetic
+    assert lib.rmnet_memory_read_workspace_bytes(1, 128, 512, 5, 30, 54, 0) > 0
+    assert lib.rmnet_memory_read_workspace_bytes(0, 128, 512, 5, 30, 54, 0) == 0
+    assert lib.rmnet_region_map_workspace_bytes(1, 2, 480, 864) > 0
+    assert lib.rmnet_flow_affine_workspace_bytes(480, 854) >= 2 * 480 * 854 * 8
+
+
+def test_invalid_arguments_are_reported_not_launched():
+    from rmnet_amd import _lib
+    lib = _lib.load()
+    assert lib.rmnet_flow_affine_f32(None, None, None, 4, 4, None, None) == -1
+    assert lib.rmnet_region_map_f32(None, 1, 2, 8, 8, 0.5, 10, 64, None, None, None, 0, 0, 16, 1, 1,
+                                    None, 0, None) == -1
+    assert lib.rmnet_memory_read_f32(None, None, None, None, 1, 128, 512, 1, 4, 4, 0, 0, 0, 0, None, None,
+                                     None, None, 0, None, 0, None) == -1
+
+
+def test_ops_reject_cpu_tensors_like_the_reference():
+    """reg_att_map_generator_cuda.cpp:14-19 -> RuntimeError for non-CUDA / non-contiguous input."""
+    import torch
+    from rmnet_amd import ops
+    from rmnet_amd.reg_att_map_generator import RegionalAttentionMapGenerator
+    with pytest.raises(RuntimeError, match='CUDA'):
+        RegionalAttentionMapGenerator()(torch.zeros(1, 2, 8, 8))
+    with pytest.raises(RuntimeError, match='CUDA'):
+        ops.memory_read(torch.zeros(1, 128, 1, 2, 2), torch.zeros(1, 512, 1, 2, 2),
+                        torch.zeros(1, 128, 2, 2), torch.zeros(1, 512, 2, 2))

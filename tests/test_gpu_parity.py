@@ -1,0 +1,359 @@
+# -*- coding: utf-8 -*-
+"""Parity of the gfx950 kernels (through the C ABI) with the oracle and the golden vectors.
+Every test here needs a real MI355X: ``pytest -m gpu``.
+
+Bars (BASELINE.json north_star): integer / index outputs (boxes, cell rectangles, 0/1 maps, the
+integer-valued flow update) bit-exact; the fp32 memory read within MR_ATOL of the oracle (fp32
+rounding only -- the kernel accumulates in fp32 MFMA, the oracle in double); end-to-end masks:
+probabilities within 1e-3 and label IoU >= 0.999 of the CPU path.
+"""
+
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+MR_ATOL = 3e-5     # absolute, for O(1) inputs / outputs
+MR_RTOL = 2e-5
+
+
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the GPU box'
+    return torch.device('cuda', 0)
+
+
+def cu(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(dev())
+
+
+def test_native_library_is_what_runs():
+    from rmnet_amd import _lib, ops
+    ops.region_map(torch.zeros(1, 2, 16, 16, device=dev()))
+    maps = open('/proc/self/maps').read()
+    assert 'librmnet_hip.so' in maps
+    assert os.path.samefile(_lib.LIB_PATH, os.path.join(os.path.dirname(_lib.__file__), 'librmnet_hip.so'))
+
+
+# ----------------------------------------------------------------------------- region map (G1)
+def _kat_mask(c):
+    m = np.zeros((c['B'], c['K'], c['H'], c['W']), np.float32)
+    for f in c['fills']:
+        m[f['b'], f['k'], f['y0']:f['y1'] + 1, f['x0']:f['x1'] + 1] = f['v']
+    return m
+
+
+def test_region_map_known_answers(golden_dir, oracle_mod):
+    from rmnet_amd.reg_att_map_generator import RegionalAttentionMapGenerator
+    gen = RegionalAttentionMapGenerator()
+    kat = json.load(open(os.path.join(golden_dir, 'region_map_kat.json')))
+    for c in kat['cases']:
+        m = _kat_mask(c)
+        att, bb = gen(cu(m), c['thr'], c['npts'], c['loose'])
+        assert bb.dtype == torch.int32 and att.dtype == torch.float32
+        assert (bb.cpu().numpy() == np.array(c['bboxes'], np.int32)).all(), c['name']
+        o_att, o_bb = oracle_mod.region_map(m, c['thr'], c['npts'], c['loose'])
+        assert np.array_equal(att.cpu().numpy(), o_att), c['name']
+
+
+@pytest.mark.parametrize('B,K,H,W', [(1, 2, 480, 864), (1, 11, 480, 854), (2, 3, 150, 250), (1, 4, 33, 47),
+                                     (1, 2, 720, 1280), (3, 2, 1, 5)])
+def test_region_map_random_soft_masks_bitexact(B, K, H, W, oracle_mod):
+    from rmnet_amd import ops
+    rng = np.random.RandomState(H * 7 + W)
+    m = np.zeros((B, K, H, W), np.float32)
+    for b in range(B):
+        for k in range(K):
+            if rng.rand() < 0.2:
+                continue                      # empty channel -> full-frame fallback
+            y0, x0 = rng.randint(0, H), rng.randint(0, W)
+            y1, x1 = rng.randint(y0, H) + 1, rng.randint(x0, W) + 1
+            m[b, k, y0:y1, x0:x1] = rng.rand(y1 - y0, x1 - x0) * 1.2
+    m[m > 1] = 0.5                            # exercise the inclusive threshold
+    o_att, o_bb = oracle_mod.region_map(m)
+    att, bb, _ = ops.region_map(cu(m))
+    assert np.array_equal(bb.cpu().numpy(), o_bb)
+    assert np.array_equal(att.cpu().numpy(), o_att)
+    # boxes-only form + cell rectangles (what the frame loop uses)
+    lw, lh = ((16 - W % 16) % 16) // 2, ((16 - H % 16) % 16) // 2
+    h, w = (H + 15) // 16, (W + 15) // 16
+    none_att, bb2, rects = ops.region_map(cu(m), want_map=False, cell_grid=(lw, lh, 16, h, w))
+    assert none_att is None and np.array_equal(bb2.cpu().numpy(), o_bb)
+    assert np.array_equal(rects.cpu().numpy(), oracle_mod.cell_rects(o_bb, lw, lh, h, w))
+    r2 = ops.boxes_to_cell_rects(bb2, lw, lh, 16, h, w, k_per_batch=K)
+    assert np.array_equal(r2.cpu().numpy(), rects.cpu().numpy())
+
+
+def test_region_map_rejects_bad_input():
+    from rmnet_amd import ops
+    x = torch.zeros(1, 2, 8, 8, device=dev())
+    with pytest.raises(RuntimeError, match='contiguous'):
+        ops.region_map(x.transpose(2, 3))
+    with pytest.raises(RuntimeError, match='float32'):
+        ops.region_map(x.double())
+
+
+# ----------------------------------------------------------------------------- flow affine (F1)
+def test_flow_affine_golden_bitexact(golden_dir):
+    from rmnet_amd import flow_affine_transformation as fat
+    g = np.load(os.path.join(golden_dir, 'flow_affine.npz'))
+    for n in sorted({k.split('.')[0] for k in g.files}):
+        out = fat.update_optical_flow(g[n + '.flow'], g[n + '.m1'], g[n + '.m2'])      # NumPy convention
+        assert isinstance(out, np.ndarray) and out.dtype == np.float32
+        assert np.array_equal(out.view(np.uint32), g[n + '.out'].view(np.uint32)), n
+        out2 = fat.update_optical_flow_cuda(cu(g[n + '.flow']), cu(g[n + '.m1']), cu(g[n + '.m2']))
+        assert np.array_equal(out2.cpu().numpy().view(np.uint32), g[n + '.out'].view(np.uint32)), n
+
+
+@pytest.mark.parametrize('H,W', [(480, 854), (720, 1280), (37, 53), (1, 1)])
+def test_flow_affine_random_bitexact(H, W, oracle_mod):
+    from rmnet_amd import ops
+    rng = np.random.RandomState(H + W)
+    for amp, jitter in [(3.0, 0.05), (60.0, 0.5), (2000.0, 3.0)]:
+        flow = ((rng.rand(H, W, 2) - 0.5) * amp).astype(np.float32)
+        m1 = (np.eye(2, 3) + (rng.rand(2, 3) - 0.5) * jitter).astype(np.float32)
+        m2 = (np.eye(2, 3) + (rng.rand(2, 3) - 0.5) * jitter).astype(np.float32)
+        want = oracle_mod.flow_affine(flow, m1, m2)
+        got = ops.flow_affine(cu(flow), cu(m1), cu(m2)).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (amp, jitter)
+
+
+# ----------------------------------------------------------------------------- memory read (M1-M3)
+def _mr(g, name, **kw):
+    from rmnet_amd import ops
+    args = [cu(g[name + '.m_key']), cu(g[name + '.m_val']), cu(g[name + '.q_key']), cu(g[name + '.q_val'])]
+    return ops.memory_read(*args, **kw)
+
+
+def test_memory_read_golden_dense(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'memory_reader.npz'))
+    for name in ['dense', 'regional', 'allmasked_query', 'peaky']:
+        out, p = _mr(g, name)
+        assert p is None
+        np.testing.assert_allclose(out.cpu().numpy(), g[name + '.mem_val'], atol=MR_ATOL, rtol=MR_RTOL,
+                                   err_msg=name)
+        out_g, _ = _mr(g, name, flags=1)          # generic kernels, same answer
+        np.testing.assert_allclose(out_g.cpu().numpy(), g[name + '.mem_val'], atol=MR_ATOL, rtol=MR_RTOL)
+
+
+def test_memory_read_golden_regional_fused_mask(golden_dir):
+    """Rectangles + (already masked OR un-masked) inputs == the reference on masked inputs."""
+    g = np.load(os.path.join(golden_dir, 'memory_reader.npz'))
+    rng = np.random.RandomState(0)
+    for name in ['regional', 'allmasked_query']:
+        mr, qr = cu(g[name + '.mem_rects']), cu(g[name + '.qry_rects'])
+        out, _ = _mr(g, name, mem_rects=mr, qry_rects=qr)
+        np.testing.assert_allclose(out.cpu().numpy(), g[name + '.mem_val'], atol=MR_ATOL, rtol=MR_RTOL)
+        # put garbage where the masks are zero: the fused kernel must ignore it
+        dirty = {}
+        for k in ('m_key', 'm_val', 'q_key', 'q_val'):
+            a = g[name + '.' + k].copy()
+            a[a == 0] = rng.randn(int((a == 0).sum())).astype(np.float32) * 3
+            dirty[k] = cu(a)
+        from rmnet_amd import ops
+        out2, _ = ops.memory_read(dirty['m_key'], dirty['m_val'], dirty['q_key'], dirty['q_val'], mr, qr)
+        np.testing.assert_allclose(out2.cpu().numpy(), g[name + '.mem_val'], atol=MR_ATOL, rtol=MR_RTOL)
+        out3, _ = ops.memory_read(dirty['m_key'], dirty['m_val'], dirty['q_key'], dirty['q_val'], mr, qr, flags=1)
+        np.testing.assert_allclose(out3.cpu().numpy(), g[name + '.mem_val'], atol=MR_ATOL, rtol=MR_RTOL)
+
+
+def test_memory_read_affinity_output(golden_dir):
+    from rmnet_amd.rmnet import MemoryReader
+    g = np.load(os.path.join(golden_dir, 'memory_reader.npz'))
+    out, p = _mr(g, 'tiny_p', want_p=True)        # De=16/Do=32 -> generic path
+    np.testing.assert_allclose(out.cpu().numpy(), g['tiny_p.mem_val'], atol=MR_ATOL, rtol=MR_RTOL)
+    np.testing.assert_allclose(p.cpu().numpy(), g['tiny_p.p'], atol=1e-6, rtol=1e-5)
+    reader = MemoryReader(return_affinity=True)   # fast path + p on request
+    out, p = reader(cu(g['dense.m_key']), cu(g['dense.m_val']), cu(g['dense.q_key']), cu(g['dense.q_val']))
+    np.testing.assert_allclose(out.cpu().numpy(), g['dense.mem_val'], atol=MR_ATOL, rtol=MR_RTOL)
+    assert p.shape == (1, 2 * 6 * 8, 6 * 8)
+    np.testing.assert_allclose(p.sum(1).cpu().numpy(), 1.0, atol=1e-5)
+
+
+def _random_case(rng, no, T, h, w, scale=0.6, regional=True):
+    mk = (rng.randn(no, 128, T, h, w) * scale).astype(np.float32)
+    mv = rng.randn(no, 512, T, h, w).astype(np.float32)
+    qk = (rng.randn(no, 128, h, w) * scale).astype(np.float32)
+    qv = rng.randn(no, 512, h, w).astype(np.float32)
+    mr = qr = None
+    if regional:
+        def rect():
+            if rng.rand() < 0.15:
+                return (1, 0, 1, 0)
+            x0, y0 = rng.randint(0, w), rng.randint(0, h)
+            return (x0, rng.randint(x0, w), y0, rng.randint(y0, h))
+        mr = np.array([[rect() for _ in range(T)] for _ in range(no)], np.int32)
+        qr = np.array([rect() for _ in range(no)], np.int32)
+    return mk, mv, qk, qv, mr, qr
+
+
+@pytest.mark.parametrize('no,T,h,w,regional', [
+    (1, 1, 4, 5, False), (2, 3, 9, 13, True), (3, 2, 12, 20, True), (1, 5, 30, 54, True),
+    (1, 4, 8, 8, True), (1, 7, 16, 24, False)])
+def test_memory_read_random_vs_oracle(no, T, h, w, regional, oracle_mod):
+    from rmnet_amd import ops
+    rng = np.random.RandomState(no * 1000 + T * 100 + h)
+    mk, mv, qk, qv, mr, qr = _random_case(rng, no, T, h, w, regional=regional)
+    if regional:
+        want, _ = oracle_mod.regional_memory_read(mk, mv, qk, qv, mr, qr)
+        got, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), cu(mr), cu(qr))
+    else:
+        want, _ = oracle_mod.memory_read(mk, mv, qk, qv)
+        got, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv))
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL)
+
+
+def test_memory_read_edge_rectangles(oracle_mod):
+    """Empty memory, empty query, full rectangles, single cells, a query count that is an exact
+    multiple of the 64-query tile (the mean slot then needs its own tile)."""
+    from rmnet_amd import ops
+    rng = np.random.RandomState(11)
+    h, w, T = 8, 16, 2
+    mk, mv, qk, qv, _, _ = _random_case(rng, 1, T, h, w, regional=False)
+    full, empty = (0, w - 1, 0, h - 1), (1, 0, 1, 0)
+    cases = [([empty, empty], full), ([full, full], empty), ([full, full], full), ([empty, (3, 3, 2, 2)], (5, 5, 7, 7)),
+             ([(0, 15, 0, 3), full], (0, 15, 0, 3)),      # 64 unmasked queries exactly
+             ([(-3, 40, -2, 90), empty], (-1, 99, 2, 5))]  # rectangles sticking out are clamped
+    for mrect, qrect in cases:
+        mr, qr = np.array([mrect], np.int32), np.array([qrect], np.int32)
+        clamp = lambda r: (max(r[0], 0), min(r[1], w - 1), max(r[2], 0), min(r[3], h - 1))
+        want, _ = oracle_mod.regional_memory_read(mk, mv, qk, qv, np.array([[clamp(r) for r in mrect]], np.int32),
+                                                  np.array([clamp(qrect)], np.int32))
+        got, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), cu(mr), cu(qr))
+        np.testing.assert_allclose(got.cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL, err_msg=str((mrect, qrect)))
+
+
+def test_memory_read_bank_strides_and_running_max(oracle_mod):
+    """A bank with capacity > T is read through the channel stride; a late, much larger logit
+    forces the deferred soft-max reference to be bumped (rescale branch)."""
+    from rmnet_amd import ops
+    rng = np.random.RandomState(5)
+    no, T, Tcap, h, w = 2, 3, 5, 6, 10
+    mk, mv, qk, qv, mr, qr = _random_case(rng, no, Tcap, h, w, regional=True)
+    mk[:, :, 2, h - 1, w - 1] = qk[:, :, 2, 3] * 9.0          # spike late in the memory: S jumps by >> 30
+    mr[:, 2] = (0, w - 1, 0, h - 1)
+    qr[:] = (0, w - 1, 0, h - 1)
+    want, _ = oracle_mod.regional_memory_read(mk[:, :, :T], mv[:, :, :T], qk, qv, mr[:, :T], qr)
+    got, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), cu(mr[:, :T]), cu(qr), T=T)
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL)
+    want_d, _ = oracle_mod.memory_read(mk[:, :, :T], mv[:, :, :T], qk, qv)
+    got_d, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), T=T)
+    np.testing.assert_allclose(got_d.cpu().numpy(), want_d, atol=MR_ATOL, rtol=MR_RTOL)
+
+
+@pytest.mark.parametrize('no,T,h,w', [(1, 5, 30, 54), (3, 20, 45, 80)])
+def test_memory_read_full_size_properties(no, T, h, w):
+    """BASELINE.json sizes (480p T=5; 720p T=20, 3 objects), checked through size-independent
+    properties instead of the (slow) oracle: regional == dense-on-premasked, soft-max rows sum to one
+    (V = 1 reads back 1), and linearity in the values."""
+    from rmnet_amd import ops
+    rng = np.random.RandomState(T)
+    g = torch.Generator(device='cpu').manual_seed(T)
+    mk = (torch.randn(no, 128, T, h, w, generator=g) * 0.6).to(dev())
+    mv = torch.randn(no, 512, T, h, w, generator=g).to(dev())
+    qk = (torch.randn(no, 128, h, w, generator=g) * 0.6).to(dev())
+    qv = torch.randn(no, 512, h, w, generator=g).to(dev())
+    mr = np.zeros((no, T, 4), np.int32)
+    qr = np.zeros((no, 4), np.int32)
+    for o in range(no):
+        for t in range(T):
+            x0, y0 = rng.randint(0, w // 2), rng.randint(0, h // 2)
+            mr[o, t] = (x0, x0 + w // 2, y0, y0 + h // 2)
+        x0, y0 = rng.randint(0, w // 3), rng.randint(0, h // 3)
+        qr[o] = (x0, x0 + w // 2, y0, y0 + h // 2)
+    mr_t, qr_t = cu(mr), cu(qr)
+    out_r, _ = ops.memory_read(mk, mv, qk, qv, mr_t, qr_t)
+    mk_m, mv_m = ops.rect_mask(mk, mr_t), ops.rect_mask(mv, mr_t)
+    qk_m = ops.rect_mask(qk.unsqueeze(2).contiguous(), qr_t.view(no, 1, 4)).squeeze(2)
+    qv_m = ops.rect_mask(qv.unsqueeze(2).contiguous(), qr_t.view(no, 1, 4)).squeeze(2)
+    out_d, _ = ops.memory_read(mk_m, mv_m, qk_m, qv_m)
+    assert torch.allclose(out_r, out_d, atol=MR_ATOL, rtol=MR_RTOL)
+    assert torch.equal(out_r[:, 512:], qv_m)                       # the cat half is q_val * box, exactly
+    ones, _ = ops.memory_read(mk, torch.ones_like(mv), qk, qv)
+    assert torch.allclose(ones[:, :512], torch.ones_like(ones[:, :512]), atol=1e-5)
+    a, _ = ops.memory_read(mk, mv, qk, qv)
+    b, _ = ops.memory_read(mk, 2.0 * mv + 1.0, qk, qv)
+    assert torch.allclose(b[:, :512], 2.0 * a[:, :512] + 1.0, atol=1e-4, rtol=1e-4)
+
+
+def test_rect_mask_vs_oracle(oracle_mod):
+    from rmnet_amd import ops
+    rng = np.random.RandomState(2)
+    x = rng.randn(3, 7, 2, 6, 9).astype(np.float32)
+    r = np.array([[(0, 8, 0, 5), (1, 0, 1, 0)], [(2, 4, 1, 3), (8, 8, 5, 5)], [(0, 0, 0, 0), (3, 7, 2, 2)]], np.int32)
+    assert np.array_equal(ops.rect_mask(cu(x), cu(r)).cpu().numpy(), oracle_mod.rect_mask(x, r))
+
+
+# ----------------------------------------------------------------------------- the frame loop (P1-P5)
+def _nets(oracle_mod):
+    from rmnet_amd import networks
+    from rmnet_amd.rmnet import RMNet
+    prod = RMNet(None)
+    networks.procedural_init_(prod)
+    ref = oracle_mod.OracleRMNet()
+    ref.load_state_dict(prod.state_dict())
+    return prod.to(dev()).eval(), ref.eval()
+
+
+def test_rmnet_clip_matches_cpu_path_and_reference(golden_dir, oracle_mod):
+    from rmnet_amd.synthetic import synthetic_clip
+    g = np.load(os.path.join(golden_dir, 'rmnet_clip.npz'))
+    prod, ref = _nets(oracle_mod)
+    N, K, H, W = int(g['clip.N']), int(g['clip.K']), int(g['clip.H']), int(g['clip.W'])
+    frames, masks, flows, n_objects = synthetic_clip(N, K, H, W, seed=int(g['clip.seed']))
+    with torch.no_grad():
+        est = prod(frames, masks, flows, n_objects, int(g['clip.memorize_every']))
+        assert est.is_cuda
+        est = est.cpu()
+        est_cpu = ref(frames, masks, flows, n_objects, int(g['clip.memorize_every']))
+    # vs the oracle's CPU path (same weights, same inputs)
+    assert float((est - est_cpu).abs().max()) < 1e-3
+    lab, lab_cpu = est.argmax(2).numpy(), est_cpu.argmax(2).numpy()
+    for k in range(1, K):
+        assert oracle_mod.iou(lab[:, 1:] == k, lab_cpu[:, 1:] == k) >= 0.999
+    # vs the reference itself (golden)
+    np.testing.assert_allclose(est[:, 1].numpy(), g['clip.est_t1'], atol=1e-3)
+    assert (lab == g['clip.est_argmax']).mean() > 0.999
+
+
+def test_rmnet_pieces_keep_reference_contract(golden_dir, oracle_mod):
+    from rmnet_amd.synthetic import synthetic_clip
+    g = np.load(os.path.join(golden_dir, 'rmnet_clip.npz'))
+    prod, ref = _nets(oracle_mod)
+    N, K, H, W = int(g['clip.N']), int(g['clip.K']), int(g['clip.H']), int(g['clip.W'])
+    frames, masks, flows, n_objects = synthetic_clip(N, K, H, W, seed=int(g['clip.seed']))
+    d = dev()
+    with torch.no_grad():
+        k4, v4, bb = prod.memorize(frames[:, 0].to(d), masks[:, 0].float().to(d), [K - 1])
+        assert (bb.cpu().numpy() == g['memorize.bboxes']).all()
+        np.testing.assert_allclose(k4.cpu().numpy(), g['memorize.k4'], atol=2e-4, rtol=1e-3)
+        np.testing.assert_allclose(v4[:, :, ::4].cpu().numpy(), g['memorize.v4_every4'], atol=2e-4, rtol=1e-3)
+        warped, valid = prod.warp(cu(g['warp.in']), cu(g['warp.flow']))
+        np.testing.assert_allclose(warped.cpu().numpy(), g['warp.out'], atol=1e-5)
+        att, box = prod.get_att_map(cu(g['warp.in']), cu(g['warp.flow']))
+        o_att, o_box = ref.get_att_map(torch.from_numpy(g['warp.in']), torch.from_numpy(g['warp.flow']))
+        assert np.array_equal(box.cpu().numpy(), o_box.numpy()) and np.array_equal(att.cpu().numpy(), o_att.numpy())
+        logit = prod.soft_aggregation(cu(g['softagg.ps']), K, [K - 1])
+        np.testing.assert_allclose(logit.cpu().numpy(), g['softagg.logit'], atol=1e-5)
+        # public segment(): reference argument list, fused kernels inside
+        k4_cpu, v4_cpu, bb_cpu = ref.memorize(frames[:, 0], masks[:, 0].float(), [K - 1])
+        att_cpu, cbb_cpu = ref.get_att_map(masks[:, 0].float(), flows[:, 1])
+        want = ref.segment(frames[:, 1], att_cpu, k4_cpu, v4_cpu, [K - 1])
+        got = prod.segment(frames[:, 1].to(d), att_cpu.to(d), k4, v4, bb.unsqueeze(2), cbb_cpu.to(d), [K - 1])
+        assert float((got.cpu() - want).abs().max()) < 2e-3
+
+
+def test_tiny_flownet_on_gpu(golden_dir):
+    from rmnet_amd import networks
+    from rmnet_amd.tiny_flownet import TinyFlowNet
+    g = np.load(os.path.join(golden_dir, 'tiny_flownet.npz'))
+    net = networks.procedural_init_(TinyFlowNet(None)).to(dev()).eval()
+    with torch.no_grad():
+        fl = net(cu(g['frames']))
+    np.testing.assert_allclose(fl.cpu().numpy(), g['flows'], atol=2e-3, rtol=1e-3)

@@ -1,0 +1,100 @@
+# -*- coding: utf-8 -*-
+"""Host-side logic that needs no GPU: product code never touches the oracle, the state-dict keys
+match the reference's, video sharding is balanced, and the N>1 gather works (gloo, world_size 2)."""
+
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, 'rmnet_amd')):
+        for fn in files:
+            if fn.endswith(('.py', '.hip', '.h', '.cpp')):
+                text = open(os.path.join(base, fn), errors='ignore').read()
+                if re.search(r'^\s*(from|import)\s+oracle|liboracle|oracle/_ref', text, flags=re.M):
+                    bad.append(fn)
+    assert not bad, bad
+
+
+def test_state_dict_keys_match_reference(golden_dir):
+    from rmnet_amd.rmnet import RMNet
+    g = np.load(os.path.join(golden_dir, 'rmnet_clip.npz'))
+    net = RMNet(None)
+    assert sorted(net.state_dict().keys()) == list(g['state_keys'])
+    # DataParallel-prefixed checkpoints load too (core/inference.py:43)
+    sd = {'module.' + k: v for k, v in net.state_dict().items()}
+    net.load_reference_state_dict(sd)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from rmnet_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(_lib.RMNetHipError, match='missing'):
+        _lib.load()
+
+
+def test_assign_videos_is_balanced_and_deterministic():
+    from rmnet_amd.dist import assign_videos, my_videos
+    costs = [67, 34, 104, 50, 80, 91, 40, 75, 69, 36, 99, 58, 84, 43, 77, 66]
+    owner = assign_videos(costs, 8)
+    assert owner == assign_videos(costs, 8)
+    loads = [sum(c for c, r in zip(costs, owner) if r == k) for k in range(8)]
+    assert max(loads) - min(loads) <= max(costs)
+    assert sorted(v for r in range(8) for v in my_videos(costs, r, 8)) == list(range(len(costs)))
+    assert assign_videos(costs, 1) == [0] * len(costs)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gather_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from rmnet_amd import dist as rd
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    rd.init_from_env(backend='gloo')
+    costs = [5, 3, 4, 2, 6]
+    mine = rd.my_videos(costs, rank, world)
+    res = {v: torch.full((costs[v], 4 + v, 6), 10 * v + 1, dtype=torch.uint8) for v in mine}
+    rd.barrier()
+    out = rd.gather_label_maps(res, len(costs))
+    mx = rd.max_over_ranks(1.0 + rank)
+    sm = rd.sum_over_ranks(2.0)
+    if rank == 0:
+        q.put((sorted(out.keys()), [tuple(out[v].shape) for v in sorted(out)],
+               [int(out[v].float().mean()) for v in sorted(out)], mx, sm))
+    else:
+        assert out == {}
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    keys, shapes, means, mx, sm = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert keys == [0, 1, 2, 3, 4]
+    assert shapes == [(5, 4, 6), (3, 5, 6), (4, 6, 6), (2, 7, 6), (6, 8, 6)]
+    assert means == [1, 11, 21, 31, 41]
+    assert mx == 2.0 and sm == 4.0

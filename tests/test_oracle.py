@@ -1,0 +1,179 @@
+# -*- coding: utf-8 -*-
+"""Pin the oracle (oracle/) against the reference: golden vectors captured from the reference's own
+code by tests/golden/make_golden.py, and hand-computed known answers for the CUDA-only region map.
+CPU only."""
+
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def _kat_mask(c):
+    m = np.zeros((c['B'], c['K'], c['H'], c['W']), np.float32)
+    for f in c['fills']:
+        m[f['b'], f['k'], f['y0']:f['y1'] + 1, f['x0']:f['x1'] + 1] = f['v']
+    return m
+
+
+def box_map(bboxes, H, W):
+    """att_map implied by boxes: 1 inside the inclusive box for k >= 1 (reg_att_map_generator.cu:81-92)."""
+    B, K, _ = bboxes.shape
+    a = np.zeros((B, K, H, W), np.float32)
+    for b in range(B):
+        for k in range(1, K):
+            x0, x1, y0, y1 = bboxes[b, k]
+            if x0 <= x1 and y0 <= y1 and x0 < W and y0 < H:
+                a[b, k, max(y0, 0):y1 + 1, max(x0, 0):x1 + 1] = 1
+    return a
+
+
+def test_region_map_known_answers(oracle_mod, golden_dir):
+    kat = json.load(open(os.path.join(golden_dir, 'region_map_kat.json')))
+    assert len(kat['cases']) >= 12
+    for c in kat['cases']:
+        att, bb = oracle_mod.region_map(_kat_mask(c), c['thr'], c['npts'], c['loose'])
+        want = np.array(c['bboxes'], np.int32)
+        assert (bb == want).all(), c['name']
+        assert (att == box_map(want, c['H'], c['W'])).all(), c['name']
+        assert (att[:, 0] == 0).all()
+
+
+def test_flow_affine_matches_reference_bitwise(oracle_mod, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'flow_affine.npz'))
+    names = sorted({k.split('.')[0] for k in g.files})
+    assert len(names) == 5
+    for n in names:
+        out = oracle_mod.flow_affine(g[n + '.flow'], g[n + '.m1'], g[n + '.m2'])
+        assert out.dtype == np.float32
+        assert np.array_equal(out.view(np.uint32), g[n + '.out'].view(np.uint32)), n
+
+
+def test_flow_affine_against_compiled_reference_random(oracle_mod):
+    """When oracle/_ref (the reference's own C++) is present, fuzz the restatement against it."""
+    import importlib.util
+    so = os.path.join(os.path.dirname(oracle_mod.__file__), '_ref', 'flow_affine_transformation.so')
+    if not os.path.exists(so):
+        pytest.skip('oracle/_ref not built (reference sources absent)')
+    spec = importlib.util.spec_from_file_location('flow_affine_transformation', so)
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    rng = np.random.RandomState(7)
+    for trial in range(6):
+        H, W = rng.randint(5, 90), rng.randint(5, 120)
+        flow = ((rng.rand(H, W, 2) - 0.5) * rng.choice([1, 20, 500])).astype(np.float32)
+        m1 = (np.eye(2, 3) + (rng.rand(2, 3) - 0.5) * rng.choice([0.1, 2.0])).astype(np.float32)
+        m2 = (np.eye(2, 3) + (rng.rand(2, 3) - 0.5) * rng.choice([0.1, 2.0])).astype(np.float32)
+        want = ref.update_optical_flow(flow, m1, m2)
+        got = oracle_mod.flow_affine(flow, m1, m2)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), trial
+
+
+# fp32 tolerance for the memory read: torch's bmm/softmax and the oracle's double accumulators
+# differ only by fp32 rounding; inputs are O(1), outputs O(1).
+MR_ATOL = 2e-5
+
+
+def test_memory_read_matches_reference(oracle_mod, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'memory_reader.npz'))
+    for name in ['dense', 'regional', 'allmasked_query', 'tiny_p', 'peaky']:
+        out, p = oracle_mod.memory_read(g[name + '.m_key'], g[name + '.m_val'], g[name + '.q_key'],
+                                        g[name + '.q_val'], want_p=(name == 'tiny_p'))
+        np.testing.assert_allclose(out, g[name + '.mem_val'], atol=MR_ATOL, rtol=1e-5, err_msg=name)
+        if name == 'tiny_p':
+            np.testing.assert_allclose(p, g['tiny_p.p'], atol=1e-6, rtol=1e-5)
+
+
+def test_regional_form_equals_premasked_dense(oracle_mod, golden_dir):
+    """Masking with rectangles then reading == the reference run on pre-masked tensors (the golden
+    'regional' inputs are already masked, so applying the rectangles again must change nothing)."""
+    g = np.load(os.path.join(golden_dir, 'memory_reader.npz'))
+    for name in ['regional', 'allmasked_query']:
+        out, _ = oracle_mod.regional_memory_read(g[name + '.m_key'], g[name + '.m_val'], g[name + '.q_key'],
+                                                 g[name + '.q_val'], g[name + '.mem_rects'],
+                                                 g[name + '.qry_rects'])
+        np.testing.assert_allclose(out, g[name + '.mem_val'], atol=MR_ATOL, rtol=1e-5)
+    # masked query cells read the mean of m_val over ALL T*h*w cells
+    mv, out = g['allmasked_query.m_val'], g['allmasked_query.mem_val']
+    mean = mv.reshape(1, 512, -1).mean(axis=2)
+    np.testing.assert_allclose(out[:, :512].reshape(1, 512, -1), mean[:, :, None].repeat(35, 2), atol=1e-5)
+
+
+def test_cell_rects_equal_nearest_downsample(oracle_mod):
+    """Box -> cell rectangle == F.interpolate(box map, 1/16, nearest) of the padded map."""
+    import torch.nn.functional as F
+    rng = np.random.RandomState(3)
+    for trial in range(40):
+        H, W = int(rng.randint(20, 200)), int(rng.randint(20, 260))
+        dh, dw = (16 - H % 16) % 16, (16 - W % 16) % 16
+        lw, lh = dw // 2, dh // 2
+        x0, y0 = int(rng.randint(0, W)), int(rng.randint(0, H))
+        x1, y1 = int(rng.randint(x0, W)), int(rng.randint(y0, H))
+        bb = np.array([[[0, 0, 0, 0], [x0, x1, y0, y1]]], np.int32)
+        att = torch.from_numpy(box_map(bb, H, W))
+        att = F.pad(att, (lw, dw - lw, lh, dh - lh))
+        low = F.interpolate(att, scale_factor=1 / 16)[0, 1].numpy()
+        h, w = low.shape
+        r = oracle_mod.cell_rects(bb, lw, lh, h, w)[0, 1]
+        want = np.zeros((h, w), np.float32)
+        if r[0] <= r[1] and r[2] <= r[3]:
+            want[r[2]:r[3] + 1, r[0]:r[1] + 1] = 1
+        assert (low == want).all(), (H, W, bb.tolist(), r.tolist())
+        assert (oracle_mod.cell_rects(bb, lw, lh, h, w)[0, 0] == [1, 0, 1, 0]).all()
+
+
+def test_pad_divide_by_matches_reference(golden_dir):
+    from rmnet_amd.helpers import pad_divide_by
+    pads = json.load(open(os.path.join(golden_dir, 'pad_divide_by.json')))
+    assert pads['480x854/16']['pad'] == [5, 5, 0, 0]
+    for key, want in pads.items():
+        hw, d = key.split('/')
+        h, w = map(int, hw.split('x'))
+        (x,), pad = pad_divide_by([torch.zeros(1, 1, h, w)], int(d), (h, w))
+        assert list(pad) == want['pad'] and list(x.shape[2:]) == want['shape'], key
+
+
+def test_oracle_rmnet_matches_reference_clip(oracle_mod, golden_dir):
+    """The plain-torch restatement of the frame loop reproduces the reference's outputs on the
+    golden clip (same procedural weights; state-dict keys identical to the reference's)."""
+    from rmnet_amd import networks
+    from rmnet_amd.synthetic import synthetic_clip
+    g = np.load(os.path.join(golden_dir, 'rmnet_clip.npz'))
+    net = oracle_mod.OracleRMNet()
+    networks.procedural_init_(net)
+    net.eval()
+    assert sorted(net.state_dict().keys()) == list(g['state_keys'])
+    csum = sum(float(v.double().abs().sum()) for v in net.state_dict().values())
+    assert abs(csum - float(g['weights_checksum'])) < 1e-6 * csum
+    N, K, H, W = int(g['clip.N']), int(g['clip.K']), int(g['clip.H']), int(g['clip.W'])
+    frames, masks, flows, n_objects = synthetic_clip(N, K, H, W, seed=int(g['clip.seed']))
+    with torch.no_grad():
+        warped, valid = net.warp(torch.from_numpy(g['warp.in']), torch.from_numpy(g['warp.flow']))
+        np.testing.assert_allclose(warped.numpy(), g['warp.out'], atol=1e-6)
+        assert (valid.numpy() == g['warp.valid']).all()
+        k4, v4, bb = net.memorize(frames[:, 0], masks[:, 0].float(), [K - 1])
+        assert (bb.numpy() == g['memorize.bboxes']).all()
+        np.testing.assert_allclose(k4.numpy(), g['memorize.k4'], atol=1e-4, rtol=1e-4)
+        np.testing.assert_allclose(v4[:, :, ::4].numpy(), g['memorize.v4_every4'], atol=1e-4, rtol=1e-4)
+        logit = net.soft_aggregation(torch.from_numpy(g['softagg.ps']), K, [K - 1])
+        np.testing.assert_allclose(logit.numpy(), g['softagg.logit'], atol=1e-5)
+        est = net(frames, masks, flows, n_objects, int(g['clip.memorize_every']))
+    np.testing.assert_allclose(est[:, 1].numpy(), g['clip.est_t1'], atol=2e-4)
+    np.testing.assert_allclose(est[:, -1, 1].numpy(), g['clip.est_last_obj1'], atol=1e-3)
+    agree = (est.argmax(2).numpy() == g['clip.est_argmax']).mean()
+    assert agree > 0.999, agree
+
+
+def test_tiny_flownet_matches_reference(golden_dir):
+    from rmnet_amd import networks
+    from rmnet_amd.tiny_flownet import TinyFlowNet
+    g = np.load(os.path.join(golden_dir, 'tiny_flownet.npz'))
+    net = TinyFlowNet(None)
+    networks.procedural_init_(net)
+    net.eval()
+    assert sorted(net.state_dict().keys()) == list(g['state_keys'])
+    with torch.no_grad():
+        fl = net(torch.from_numpy(g['frames']))
+    np.testing.assert_allclose(fl.numpy(), g['flows'], atol=1e-4, rtol=1e-4)
