@@ -7,8 +7,8 @@
 //     x1 = round(M1[0]*x1 + M1[1]*y1 + M1[2])
 //     y1 = round(M1[3]*x1 + M1[4]*y1 + M1[5])     <- uses the UPDATED x1 (.cpp:72-73), kept
 //     clamp to [0, W-1] / [0, H-1];  out = (x1 - x2, y1 - y2)
-// __fmul_rn/__fadd_rn are never contracted into FMAs, so the result is bit-identical to the
-// x86-64 build of the reference (g++ -O2 emits no FMA); roundf = half away from zero = std::round.
+// Compiled with FP contraction off (pragma below), so the result is bit-identical to the
+// x86-64 build of the reference (g++ -O2 emits no FMA); rounding is an exact half-away-from-zero.
 //
 // The reference is a single-threaded scalar loop inside DataLoader workers.  Here it is a
 // streaming kernel: one pixel (8 bytes in, 8 bytes out) per lane, one row band per block, so no
@@ -16,10 +16,25 @@
 // Algorithmic HBM bytes: 16*H*W + 48.
 #include "common.h"
 
+// hipcc defaults to -ffp-contract=fast; contraction is switched off for this translation unit to
+// keep one rounding per operation.  (HIP's __fmul_rn/__fadd_rn are inline header functions compiled
+// BEFORE this pragma, so they still fuse -- the kernel uses plain operators instead.)
+#pragma clang fp contract(off)
+
 namespace rmnet {
 namespace {
 
 constexpr int kThreads = 256;
+
+// std::round (half away from zero), exactly.  The device library's roundf evaluates
+// trunc(x + copysign(0.5, x)), which rounds 3.4999998f up to 4 (the add is inexact); x - trunc(x)
+// is always exact, so this form has no such case.
+__device__ inline float round_half_away(float x) {
+  float t = truncf(x);
+  const float d = x - t;
+  if (fabsf(d) >= 0.5f) t += copysignf(1.0f, x);
+  return t;
+}
 
 __global__ __launch_bounds__(kThreads) void flow_affine_kernel(const float2* __restrict__ flow,
                                                                const float* __restrict__ m1,
@@ -36,17 +51,18 @@ __global__ __launch_bounds__(kThreads) void flow_affine_kernel(const float2* __r
     const float fi = (float)y;
     const size_t idx = (size_t)y * W + x;
     const float2 f = flow[idx];
-    float x2 = roundf(__fadd_rn(__fadd_rn(__fmul_rn(b0, fj), __fmul_rn(b1, fi)), b2));
-    float y2 = roundf(__fadd_rn(__fadd_rn(__fmul_rn(b3, fj), __fmul_rn(b4, fi)), b5));
-    float x1 = __fadd_rn(fj, f.x);
-    float y1 = __fadd_rn(fi, f.y);
-    x1 = roundf(__fadd_rn(__fadd_rn(__fmul_rn(a0, x1), __fmul_rn(a1, y1)), a2));
-    y1 = roundf(__fadd_rn(__fadd_rn(__fmul_rn(a3, x1), __fmul_rn(a4, y1)), a5));
+    // plain operators: they, unlike the header-defined __fmul_rn/__fadd_rn, obey the pragma above
+    float x2 = round_half_away(b0 * fj + b1 * fi + b2);
+    float y2 = round_half_away(b3 * fj + b4 * fi + b5);
+    float x1 = fj + f.x;
+    float y1 = fi + f.y;
+    x1 = round_half_away(a0 * x1 + a1 * y1 + a2);
+    y1 = round_half_away(a3 * x1 + a4 * y1 + a5);
     x1 = x1 < 0.0f ? 0.0f : (x1 >= fw ? fw1 : x1);
     y1 = y1 < 0.0f ? 0.0f : (y1 >= fh ? fh1 : y1);
     x2 = x2 < 0.0f ? 0.0f : (x2 >= fw ? fw1 : x2);
     y2 = y2 < 0.0f ? 0.0f : (y2 >= fh ? fh1 : y2);
-    out[idx] = make_float2(__fsub_rn(x1, x2), __fsub_rn(y1, y2));
+    out[idx] = make_float2(x1 - x2, y1 - y2);
   }
 }
 

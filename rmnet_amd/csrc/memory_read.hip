@@ -55,6 +55,7 @@ constexpr int kPS = 80;          // P tile row stride
 constexpr int kMaxT = 512;
 constexpr int kMaxSplits = 64;
 constexpr int kTargetSlots = 256;  // workgroups per launch the split heuristic aims for
+constexpr int kMinTilesPerSplit = 4;  // each split must amortise its prologue + 128 KB partial over >= 4 tiles
 constexpr float kDefer = 30.0f;
 constexpr int kThreads = 256;
 
@@ -128,6 +129,7 @@ __device__ inline Plan make_plan(const KArgs& a, int o, int* prefix) {
   int ns = kTargetSlots / (p.nqt * a.no);
   if (ns > a.slots / p.nqt) ns = a.slots / p.nqt;
   if (ns > kMaxSplits) ns = kMaxSplits;
+  if (ns > p.njt / kMinTilesPerSplit) ns = p.njt / kMinTilesPerSplit;
   if (ns < 1) ns = 1;
   if (ns > p.njt) ns = p.njt;  // 0 when there is nothing to read
   p.nsplit = ns;
@@ -329,52 +331,99 @@ __global__ __launch_bounds__(kThreads, 1) void mr_main(const KArgs a) {
 
 constexpr int kCombCh = 64;  // read-out channels (and as many q_val channels) per combine block
 
+// Merge the per-split partials.  grid = (nqt_max + cell tiles, kDo / kCombCh, no):
+//   blocks [0, nqt_max)   : one compacted query tile each (exit if beyond the live tile count).
+//        All 64 queries of a block share the tile, so the split weights
+//        w[s][q] = exp(m_s - m_tot) / l_tot  are built by 4 lanes per query in parallel (short
+//        dependent-load chains), then every thread streams 16 channels x nsplit partial values
+//        (coalesced 256 B rows) and scatters the result to the query's cell, together with the
+//        q_val half of the cat (models/rmnet.py:163).
+//   blocks [nqt_max, ...) : one tile of 64 grid cells each; cells OUTSIDE the query box get the
+//        mean-slot vector (uniform soft-max, see file header) and q_val * 0.  Skipped when dense.
 template <bool REGIONAL>
-__global__ __launch_bounds__(kThreads) void mr_combine(const KArgs a) {
+__global__ __launch_bounds__(kThreads) void mr_combine(const KArgs a, int nqt_max) {
   __shared__ float Wt[kMaxSplits][kQT];
+  __shared__ float red[4][kQT];
   __shared__ int prefix[kMaxT + 4];
   const int tid = threadIdx.x, o = blockIdx.z;
   const Plan pl = make_plan<REGIONAL>(a, o, prefix);
-  const int ci = tid & 63, cg = tid >> 6;
-  const int cell = blockIdx.x * kQT + ci;
-  const bool live = cell < a.hw;
-  bool inside = true;
-  int n = cell;
-  if (REGIONAL && live) {
-    const int cy = cell / a.w, cx = cell - cy * a.w;
-    inside = pl.qr.contains(cy, cx);
-    n = inside ? (cy - pl.qr.cy0) * pl.qr.width() + (cx - pl.qr.cx0) : pl.Mq;  // mean slot
-  }
-  if (!live) n = 0;
-  const int qt = n >> 6, qi = n & 63;
+  const int qi = tid & 63, sl = tid >> 6;
   const float n_out = (float)(a.T * a.hw - pl.M);
   const float* ml = a.ws_ml + (size_t)o * a.slots * 2 * kQT;
-  if (cg == 0) {
-    float mtot = n_out > 0.0f ? 0.0f : -INFINITY;
-    for (int s = 0; s < pl.nsplit; ++s) mtot = fmaxf(mtot, ml[((size_t)(s * pl.nqt + qt) * 2) * kQT + qi]);
-    float ltot = n_out > 0.0f ? n_out * expf(-mtot) : 0.0f;
-    for (int s = 0; s < pl.nsplit; ++s) {
-      const float* e = ml + ((size_t)(s * pl.nqt + qt) * 2) * kQT;
-      const float wgt = expf(e[qi] - mtot);
-      Wt[s][ci] = wgt;
-      ltot += e[kQT + qi] * wgt;
-    }
-    const float inv = 1.0f / ltot;
-    for (int s = 0; s < pl.nsplit; ++s) Wt[s][ci] *= inv;
-  }
-  __syncthreads();
-  if (!live) return;
   const float* wo = a.ws_o + (size_t)o * a.slots * (size_t)kDo * kQT;
-  float* out = a.out + (size_t)o * 2 * kDo * a.hw + cell;
-  const float* qv = a.qv + (size_t)o * kDo * a.hw + cell;
-  for (int dd = cg; dd < kCombCh; dd += 4) {
-    const int d = blockIdx.y * kCombCh + dd;
-    float acc = 0.0f;
-    for (int s = 0; s < pl.nsplit; ++s)
-      acc += Wt[s][ci] * wo[((size_t)(s * pl.nqt + qt) * kDo + d) * kQT + qi];
-    out[(size_t)d * a.hw] = acc;
-    const float v = qv[(size_t)d * a.hw];
-    out[(size_t)(kDo + d) * a.hw] = inside ? v : v * 0.0f;  // cat(mem, q_val * box), :163 / :358
+  const bool fill = (int)blockIdx.x >= nqt_max;   // masked-cell filler block
+  const int qt = fill ? (pl.Mq >> 6) : (int)blockIdx.x;
+  if (!fill && qt >= pl.nqt) return;
+  if (fill && (!REGIONAL || pl.Mq >= a.hw)) return;   // nothing is masked
+
+  // ---- split weights for the 64 queries of tile qt
+  float mloc = -INFINITY;
+  for (int s = sl; s < pl.nsplit; s += 4) mloc = fmaxf(mloc, ml[((size_t)(s * pl.nqt + qt) * 2) * kQT + qi]);
+  red[sl][qi] = mloc;
+  __syncthreads();
+  float mtot = fmaxf(fmaxf(red[0][qi], red[1][qi]), fmaxf(red[2][qi], red[3][qi]));
+  if (n_out > 0.0f) mtot = fmaxf(mtot, 0.0f);        // the N_out masked memory cells have S = 0
+  __syncthreads();
+  float lloc = 0.0f;
+  for (int s = sl; s < pl.nsplit; s += 4) {
+    const float* e = ml + ((size_t)(s * pl.nqt + qt) * 2) * kQT;
+    const float wgt = expf(e[qi] - mtot);
+    Wt[s][qi] = wgt;
+    lloc += e[kQT + qi] * wgt;
+  }
+  red[sl][qi] = lloc;
+  __syncthreads();
+  float ltot = red[0][qi] + red[1][qi] + red[2][qi] + red[3][qi];
+  if (n_out > 0.0f) ltot += n_out * expf(-mtot);
+  const float inv = 1.0f / ltot;
+  for (int s = sl; s < pl.nsplit; s += 4) Wt[s][qi] *= inv;
+  __syncthreads();
+
+  const int d0 = blockIdx.y * kCombCh;
+  if (!fill) {
+    const int n = qt * kQT + qi;
+    if (n >= pl.Mq) return;                          // padding / mean slot: not a real cell
+    const int cell = REGIONAL ? query_cell(pl, a.w, n) : n;
+    float* out = a.out + (size_t)o * 2 * kDo * a.hw + cell;
+    const float* qv = a.qv + (size_t)o * kDo * a.hw + cell;
+    for (int dd = sl; dd < kCombCh; dd += 4) {
+      const int d = d0 + dd;
+      const float* src = wo + ((size_t)qt * kDo + d) * kQT + qi;
+      const size_t sstride = (size_t)pl.nqt * kDo * kQT;
+      float acc0 = 0.0f, acc1 = 0.0f;
+      int s = 0;
+      for (; s + 1 < pl.nsplit; s += 2) {
+        acc0 += Wt[s][qi] * src[(size_t)s * sstride];
+        acc1 += Wt[s + 1][qi] * src[(size_t)(s + 1) * sstride];
+      }
+      if (s < pl.nsplit) acc0 += Wt[s][qi] * src[(size_t)s * sstride];
+      out[(size_t)d * a.hw] = acc0 + acc1;
+      out[(size_t)(kDo + d) * a.hw] = qv[(size_t)d * a.hw];          // cat(mem, q_val), :163
+    }
+  } else {
+    // mean-slot vector for this block's channels -> LDS, then broadcast to the masked cells
+    __shared__ float meanv[kCombCh];
+    const int mq = pl.Mq & 63;
+    if (tid < kCombCh) {
+      const int d = d0 + tid;
+      const float* src = wo + ((size_t)qt * kDo + d) * kQT + mq;
+      const size_t sstride = (size_t)pl.nqt * kDo * kQT;
+      float acc = 0.0f;
+      for (int s = 0; s < pl.nsplit; ++s) acc += Wt[s][mq] * src[(size_t)s * sstride];
+      meanv[tid] = acc;
+    }
+    __syncthreads();
+    const int cell = ((int)blockIdx.x - nqt_max) * kQT + qi;
+    if (cell >= a.hw) return;
+    const int cy = cell / a.w, cx = cell - cy * a.w;
+    if (pl.qr.contains(cy, cx)) return;              // written by the query-tile blocks
+    float* out = a.out + (size_t)o * 2 * kDo * a.hw + cell;
+    const float* qv = a.qv + (size_t)o * kDo * a.hw + cell;
+    for (int dd = sl; dd < kCombCh; dd += 4) {
+      const int d = d0 + dd;
+      out[(size_t)d * a.hw] = meanv[dd];
+      out[(size_t)(kDo + d) * a.hw] = qv[(size_t)d * a.hw] * 0.0f;   // q_val * box (:358), x*0 semantics
+    }
   }
 }
 
@@ -526,7 +575,9 @@ int launch_memory_read(const MemReadArgs& m, hipStream_t st) {
     a.ws_o = static_cast<float*>(m.ws);
     a.ws_ml = reinterpret_cast<float*>(static_cast<char*>(m.ws) +
                                        align256((size_t)m.no * a.slots * kDo * kQT * 4));
-    dim3 g1(a.slots, m.no), g2((unsigned)((hw + kQT - 1) / kQT), kDo / kCombCh, m.no);
+    const int nqt_max = (int)((hw + 1 + kQT - 1) / kQT);
+    dim3 g1(a.slots, m.no);
+    dim3 g2((unsigned)(nqt_max + (regional ? (hw + kQT - 1) / kQT : 0)), kDo / kCombCh, m.no);
     if (m.ev_start && hipEventRecord(m.ev_start, st) != hipSuccess) return RMNET_E_LAUNCH;
     if (regional)
       hipLaunchKernelGGL(mr_main<true>, g1, dim3(kThreads), 0, st, a);
@@ -535,9 +586,9 @@ int launch_memory_read(const MemReadArgs& m, hipStream_t st) {
     if (int e = check_launch()) return e;
     if (m.ev_mid && hipEventRecord(m.ev_mid, st) != hipSuccess) return RMNET_E_LAUNCH;
     if (regional)
-      hipLaunchKernelGGL(mr_combine<true>, g2, dim3(kThreads), 0, st, a);
+      hipLaunchKernelGGL(mr_combine<true>, g2, dim3(kThreads), 0, st, a, nqt_max);
     else
-      hipLaunchKernelGGL(mr_combine<false>, g2, dim3(kThreads), 0, st, a);
+      hipLaunchKernelGGL(mr_combine<false>, g2, dim3(kThreads), 0, st, a, nqt_max);
     if (int e = check_launch()) return e;
     if (m.ev_end && hipEventRecord(m.ev_end, st) != hipSuccess) return RMNET_E_LAUNCH;
     if (!m.p_out) return RMNET_OK;

@@ -335,7 +335,7 @@ def test_rmnet_pieces_keep_reference_contract(golden_dir, oracle_mod):
         np.testing.assert_allclose(k4.cpu().numpy(), g['memorize.k4'], atol=2e-4, rtol=1e-3)
         np.testing.assert_allclose(v4[:, :, ::4].cpu().numpy(), g['memorize.v4_every4'], atol=2e-4, rtol=1e-3)
         warped, valid = prod.warp(cu(g['warp.in']), cu(g['warp.flow']))
-        np.testing.assert_allclose(warped.cpu().numpy(), g['warp.out'], atol=1e-5)
+        np.testing.assert_allclose(warped.cpu().numpy(), g['warp.out'], atol=1e-4)   # torch grid_sample, GPU vs CPU
         att, box = prod.get_att_map(cu(g['warp.in']), cu(g['warp.flow']))
         o_att, o_box = ref.get_att_map(torch.from_numpy(g['warp.in']), torch.from_numpy(g['warp.flow']))
         assert np.array_equal(box.cpu().numpy(), o_box.numpy()) and np.array_equal(att.cpu().numpy(), o_att.numpy())
