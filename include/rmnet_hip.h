@@ -113,6 +113,31 @@ int rmnet_memory_read_f32_ev(const float *m_key, const float *m_val, const float
                              int flags, void *workspace, size_t workspace_bytes, void *stream,
                              void *ev_start, void *ev_mid, void *ev_end);
 
+/* ---------------------------------------------------------------------------------------------
+ * P1/P2 + M1-M3  Regional memory BANK: the form the frame loop uses.
+ * Replaces: the K-slot padding, box masking and per-frame torch.cat of the whole memory
+ *           (models/rmnet.py:191-205, 239-248, 416-426) plus the read itself (:361).
+ * A bank is an opaque device buffer of rmnet_bank_bytes(no, Tcap, h, w) bytes holding, per object
+ * and per memorised frame ("slot"), only the cells inside that frame's box, already split into
+ * fp16 hi/lo planes in the MFMA fragment order (see csrc/bank.hip).  De = 128, Do = 512.
+ *   rmnet_bank_append_f32: write frame `slot` from k4 [no,128,h,w] / v4 [no,512,h,w] (fp32, the
+ *       KeyValue outputs, UN-masked) and its cell rectangles rects [no,4] (NULL = whole frame).
+ *       A slot may be overwritten (the tentative "previous frame" slot of models/rmnet.py:416-426).
+ *   rmnet_bank_read_f32: read the first T slots with q_key [no,128,h,w], q_val [no,512,h,w] and
+ *       query rectangles qry_rects [no,4] (NULL = all cells) -> mem_val [no,1024,h,w], identical in
+ *       meaning to rmnet_memory_read_f32 with the same rectangles.  Arithmetic: split-fp16 MFMA
+ *       (hi*hi + hi*lo + lo*hi), fp32 accumulate -- fp32-class accuracy; |values| must stay below
+ *       ~1.3e5 (they saturate beyond).  ev_* as in rmnet_memory_read_f32_ev (may be NULL).
+ * ------------------------------------------------------------------------------------------- */
+size_t rmnet_bank_bytes(int no, int Tcap, int h, int w);
+int rmnet_bank_append_f32(void *bank, int no, int Tcap, int h, int w, int slot, const float *k4,
+                          const float *v4, const int32_t *rects, void *stream);
+size_t rmnet_bank_read_workspace_bytes(int no, int h, int w);
+int rmnet_bank_read_f32(const void *bank, int no, int Tcap, int h, int w, int T,
+                        const float *q_key, const float *q_val, const int32_t *qry_rects,
+                        float *mem_val, void *workspace, size_t workspace_bytes, void *stream,
+                        void *ev_start, void *ev_mid, void *ev_end);
+
 /* M2/M3 standalone: y = x * rectangle-mask, x [n, C, T, h, w] contiguous, rects [n, T, 4].
  * Replaces the elementwise multiplies at models/rmnet.py:247-248 and :357-358 when a caller
  * wants the masked tensors themselves (e.g. RMNet.memorize's return values). */

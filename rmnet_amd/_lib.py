@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'librmnet_hip.so')
+LIB_PATH = os.environ.get('RMNET_HIP_LIB') or os.path.join(_HERE, 'librmnet_hip.so')   # override: experiments only
 
 c_f32p = ctypes.c_void_p   # device pointers travel as integers
 c_i32p = ctypes.c_void_p
@@ -37,6 +37,15 @@ SIGNATURES = {
         ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong,
         ctypes.c_longlong, c_f32p, c_f32p, c_i32p, c_i32p, ctypes.c_int, ctypes.c_void_p,
         ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    'rmnet_bank_bytes': (ctypes.c_size_t, [ctypes.c_int] * 4),
+    'rmnet_bank_append_f32': (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p,
+        c_f32p, c_i32p, ctypes.c_void_p]),
+    'rmnet_bank_read_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 3),
+    'rmnet_bank_read_f32': (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p,
+        c_f32p, c_i32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p]),
     'rmnet_rect_mask_f32': (ctypes.c_int, [
         c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i32p, c_f32p,
         ctypes.c_void_p]),

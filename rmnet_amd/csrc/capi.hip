@@ -77,6 +77,36 @@ int rmnet_memory_read_f32(const float* m_key, const float* m_val, const float* q
                                   nullptr, nullptr, nullptr);
 }
 
+size_t rmnet_bank_bytes(int no, int Tcap, int h, int w) {
+  if (no <= 0 || Tcap <= 0 || h <= 0 || w <= 0) return 0;
+  return bank_bytes(no, Tcap, h, w);
+}
+
+int rmnet_bank_append_f32(void* bank, int no, int Tcap, int h, int w, int slot, const float* k4,
+                          const float* v4, const int32_t* rects, void* stream) {
+  return launch_bank_append(bank, no, Tcap, h, w, slot, k4, v4, rects, static_cast<hipStream_t>(stream));
+}
+
+size_t rmnet_bank_read_workspace_bytes(int no, int h, int w) {
+  if (no <= 0 || h <= 0 || w <= 0) return 0;
+  return bank_read_ws_bytes(no, h, w);
+}
+
+int rmnet_bank_read_f32(const void* bank, int no, int Tcap, int h, int w, int T, const float* q_key,
+                        const float* q_val, const int32_t* qry_rects, float* mem_val,
+                        void* workspace, size_t workspace_bytes, void* stream, void* ev_start,
+                        void* ev_mid, void* ev_end) {
+  BankReadArgs a;
+  a.bank = bank; a.no = no; a.Tcap = Tcap; a.h = h; a.w = w; a.T = T;
+  a.qk = q_key; a.qv = q_val; a.qry_rects = qry_rects; a.out = mem_val;
+  a.ws_o = nullptr; a.ws_ml = nullptr; a.slots = 0;
+  a.ws = workspace; a.ws_bytes = workspace_bytes;
+  a.ev_start = static_cast<hipEvent_t>(ev_start);
+  a.ev_mid = static_cast<hipEvent_t>(ev_mid);
+  a.ev_end = static_cast<hipEvent_t>(ev_end);
+  return launch_bank_read(a, static_cast<hipStream_t>(stream));
+}
+
 int rmnet_rect_mask_f32(const float* x, int n, int C, int T, int h, int w, const int32_t* rects,
                         float* y, void* stream) {
   return launch_rect_mask(x, n, C, T, h, w, rects, y, static_cast<hipStream_t>(stream));

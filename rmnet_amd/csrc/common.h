@@ -82,6 +82,53 @@ struct MemReadArgs {
 size_t memory_read_ws_bytes(int no, int De, int Do, int T, int h, int w, int flags);
 int launch_memory_read(const MemReadArgs& a, hipStream_t st);
 
+// ---- split-fp16 memory bank (bank.hip) -------------------------------------------------------
+struct BankView {
+  char *kh, *kl;   // [no][Tcap][hwp][128] fp16 hi / lo  (cell-major keys)
+  char *vh, *vl;   // [no][Tcap][512][hwp] fp16 hi / lo  (channel-major values, cells permuted per 32)
+  int32_t* area;   // [no][Tcap] cells inside the box of each memorised frame
+  int no, Tcap, h, w, hw, hwp;
+};
+BankView bank_view(void* base, int no, int Tcap, int h, int w);
+size_t bank_bytes(int no, int Tcap, int h, int w);
+
+// Split heuristic shared by the read kernels and the combine kernel (must agree exactly).
+constexpr int kSplitTargetSlots = 256;   // workgroups per launch to aim for (one per CU)
+constexpr int kSplitMinTiles = 4;        // a split must amortise its prologue + 128 KB partial
+constexpr int kSplitMax = 64;
+struct BankPlan { int nqt, nsplit; };
+__host__ __device__ inline BankPlan bank_plan(int Mq, int hw, int njt, int no, int slots) {
+  BankPlan p;
+  p.nqt = (Mq + (Mq < hw ? 1 : 0) + 63) / 64;   // +1: the mean slot for masked query cells
+  if (p.nqt < 1) p.nqt = 1;
+  int ns = kSplitTargetSlots / (p.nqt * no);
+  if (ns > slots / p.nqt) ns = slots / p.nqt;
+  if (ns > kSplitMax) ns = kSplitMax;
+  if (ns > njt / kSplitMinTiles) ns = njt / kSplitMinTiles;
+  if (ns < 1) ns = 1;
+  if (ns > njt) ns = njt;   // 0 when there is nothing to read
+  p.nsplit = ns;
+  return p;
+}
+
+struct BankReadArgs {
+  const void* bank;
+  int no, Tcap, h, w, T;
+  const float *qk, *qv;
+  const int32_t* qry_rects;
+  float* out;
+  float *ws_o, *ws_ml;
+  int slots;
+  void* ws;
+  size_t ws_bytes;
+  hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_end = nullptr;
+};
+int launch_bank_append(void* bank, int no, int Tcap, int h, int w, int slot, const float* k4,
+                       const float* v4, const int32_t* rects, hipStream_t st);
+int launch_bank_main(const BankReadArgs& a, hipStream_t st);   // bank.hip: the read kernel only
+size_t bank_read_ws_bytes(int no, int h, int w);
+int launch_bank_read(BankReadArgs& a, hipStream_t st);         // memory_read.hip: main + combine
+
 inline int check_launch() { return hipGetLastError() == hipSuccess ? RMNET_OK : RMNET_E_LAUNCH; }
 
 }  // namespace rmnet

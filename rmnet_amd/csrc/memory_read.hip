@@ -53,9 +53,8 @@ constexpr int kKS = 48;          // K tile row stride (floats): 32 + 16 -> lane 
 constexpr int kVS = 34;          // V tile row stride: 16 rows x {0,1} -> 32 distinct banks
 constexpr int kPS = 80;          // P tile row stride
 constexpr int kMaxT = 512;
-constexpr int kMaxSplits = 64;
-constexpr int kTargetSlots = 256;  // workgroups per launch the split heuristic aims for
-constexpr int kMinTilesPerSplit = 4;  // each split must amortise its prologue + 128 KB partial over >= 4 tiles
+constexpr int kMaxSplits = kSplitMax;
+constexpr int kTargetSlots = kSplitTargetSlots;
 constexpr float kDefer = 30.0f;
 constexpr int kThreads = 256;
 
@@ -72,6 +71,8 @@ struct KArgs {
   long long mk_cs, mk_os, mv_cs, mv_os;
   int slots;                 // workgroup slots per object (grid.x of mr_main)
   float sqrt_de;
+  const int32_t* bank_area;  // non-null: memory side comes from a bank (areas [no][bank_tcap])
+  int bank_tcap;
 };
 
 struct Plan {
@@ -89,7 +90,7 @@ template <bool REGIONAL>
 __device__ inline Plan make_plan(const KArgs& a, int o, int* prefix) {
   Plan p;
   const int tid = threadIdx.x;
-  if (REGIONAL) {
+  if (REGIONAL && a.mem_rects) {
     if (tid < RMNET_WAVE) {
       int carry = 0;
       for (int base = 0; base < a.T; base += RMNET_WAVE) {
@@ -115,24 +116,32 @@ __device__ inline Plan make_plan(const KArgs& a, int o, int* prefix) {
     }
     __syncthreads();
     p.M = prefix[a.T];
+  } else {
+    p.M = a.T * a.hw;
+  }
+  if (REGIONAL) {
     const int32_t* q = a.qry_rects + (size_t)o * 4;
     p.qr = Rect{max(q[0], 0), min(q[1], a.w - 1), max(q[2], 0), min(q[3], a.h - 1)};
     p.Mq = p.qr.area();
   } else {
-    p.M = a.T * a.hw;
     p.Mq = a.hw;
     p.qr = Rect{0, a.w - 1, 0, a.h - 1};
   }
-  p.nqt = (p.Mq + (p.Mq < a.hw ? 1 : 0) + kQT - 1) / kQT;
-  if (p.nqt < 1) p.nqt = 1;
-  p.njt = (p.M + kJT - 1) / kJT;
-  int ns = kTargetSlots / (p.nqt * a.no);
-  if (ns > a.slots / p.nqt) ns = a.slots / p.nqt;
-  if (ns > kMaxSplits) ns = kMaxSplits;
-  if (ns > p.njt / kMinTilesPerSplit) ns = p.njt / kMinTilesPerSplit;
-  if (ns < 1) ns = 1;
-  if (ns > p.njt) ns = p.njt;  // 0 when there is nothing to read
-  p.nsplit = ns;
+  if (a.bank_area) {   // memory side of a split-fp16 bank: cells and 32-cell tiles per frame
+    int m = 0, tiles = 0;
+    for (int t = 0; t < a.T; ++t) {
+      const int ar = a.bank_area[(size_t)o * a.bank_tcap + t];
+      m += ar;
+      tiles += (ar + kJT - 1) / kJT;
+    }
+    p.M = m;
+    p.njt = tiles;
+  } else {
+    p.njt = (p.M + kJT - 1) / kJT;
+  }
+  const BankPlan bp = bank_plan(p.Mq, a.hw, p.njt, a.no, a.slots);
+  p.nqt = bp.nqt;
+  p.nsplit = bp.nsplit;
   return p;
 }
 
@@ -313,15 +322,14 @@ __global__ __launch_bounds__(kThreads, 1) void mr_main(const KArgs a) {
     }
   }
 
-  // ---- partial (O, m, l) -> workspace slot L
+  // ---- partial (O, m, l) -> workspace slot L, layout [query][channel]: a lane owns 4 consecutive
+  //      channels of one query, so every store is 16 bytes and a lane group fills 64 contiguous bytes
   float* wo = a.ws_o + ((size_t)o * a.slots + L) * (size_t)kDo * kQT;
 #pragma unroll
   for (int dt = 0; dt < 8; ++dt)
 #pragma unroll
     for (int it = 0; it < 4; ++it)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        wo[(size_t)(wave * 128 + dt * 16 + 4 * g + r) * kQT + it * 16 + l15] = acc[dt][it][r];
+      *reinterpret_cast<f32x4*>(wo + (size_t)(it * 16 + l15) * kDo + wave * 128 + dt * 16 + 4 * g) = acc[dt][it];
   if (g == 0) {
     float* wm = a.ws_ml + ((size_t)o * a.slots + L) * 2 * kQT;
     wm[wave * 16 + l15] = mref;
@@ -331,26 +339,28 @@ __global__ __launch_bounds__(kThreads, 1) void mr_main(const KArgs a) {
 
 constexpr int kCombCh = 64;  // read-out channels (and as many q_val channels) per combine block
 
-// Merge the per-split partials.  grid = (nqt_max + cell tiles, kDo / kCombCh, no):
-//   blocks [0, nqt_max)   : one compacted query tile each (exit if beyond the live tile count).
-//        All 64 queries of a block share the tile, so the split weights
-//        w[s][q] = exp(m_s - m_tot) / l_tot  are built by 4 lanes per query in parallel (short
-//        dependent-load chains), then every thread streams 16 channels x nsplit partial values
-//        (coalesced 256 B rows) and scatters the result to the query's cell, together with the
-//        q_val half of the cat (models/rmnet.py:163).
+// Merge the per-split partials (workspace layout [slot][query][channel]).
+// grid = (nqt_max + cell tiles, kDo / kCombCh, no):
+//   blocks [0, nqt_max)   : one compacted query tile x 64 channels each (exit beyond the live tiles).
+//        The split weights w[s][q] = exp(m_s - m_tot) / l_tot are built by 4 lanes per query; then
+//        thread (channel, query group) accumulates 16 queries x nsplit partial values with fully
+//        independent, coalesced 256-byte loads, the 64x64 tile is transposed through LDS and
+//        scattered to the queries' cells (coalesced along cells) with the q_val half of the cat
+//        (models/rmnet.py:163).
 //   blocks [nqt_max, ...) : one tile of 64 grid cells each; cells OUTSIDE the query box get the
 //        mean-slot vector (uniform soft-max, see file header) and q_val * 0.  Skipped when dense.
 template <bool REGIONAL>
 __global__ __launch_bounds__(kThreads) void mr_combine(const KArgs a, int nqt_max) {
   __shared__ float Wt[kMaxSplits][kQT];
   __shared__ float red[4][kQT];
+  __shared__ float Tt[kQT][kCombCh + 1];
   __shared__ int prefix[kMaxT + 4];
   const int tid = threadIdx.x, o = blockIdx.z;
   const Plan pl = make_plan<REGIONAL>(a, o, prefix);
   const int qi = tid & 63, sl = tid >> 6;
   const float n_out = (float)(a.T * a.hw - pl.M);
-  const float* ml = a.ws_ml + (size_t)o * a.slots * 2 * kQT;
-  const float* wo = a.ws_o + (size_t)o * a.slots * (size_t)kDo * kQT;
+  const float* __restrict__ ml = a.ws_ml + (size_t)o * a.slots * 2 * kQT;
+  const float* __restrict__ wo = a.ws_o + (size_t)o * a.slots * (size_t)kDo * kQT;
   const bool fill = (int)blockIdx.x >= nqt_max;   // masked-cell filler block
   const int qt = fill ? (pl.Mq >> 6) : (int)blockIdx.x;
   if (!fill && qt >= pl.nqt) return;
@@ -380,48 +390,54 @@ __global__ __launch_bounds__(kThreads) void mr_combine(const KArgs a, int nqt_ma
   __syncthreads();
 
   const int d0 = blockIdx.y * kCombCh;
+  const size_t sstride = (size_t)pl.nqt * kDo * kQT;   // between the splits of one query tile
   if (!fill) {
+    {  // accumulate: thread = (channel di, query group qs), queries qs + 4k
+      const int di = tid & 63, qs = tid >> 6;
+      float acc[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
+      const float* __restrict__ src = wo + (size_t)qt * kDo * kQT + d0 + di;
+      for (int s = 0; s < pl.nsplit; ++s) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          acc[k] += Wt[s][qs + 4 * k] * src[(size_t)s * sstride + (size_t)(qs + 4 * k) * kDo];
+      }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) Tt[qs + 4 * k][di] = acc[k];
+    }
+    __syncthreads();
     const int n = qt * kQT + qi;
     if (n >= pl.Mq) return;                          // padding / mean slot: not a real cell
     const int cell = REGIONAL ? query_cell(pl, a.w, n) : n;
-    float* out = a.out + (size_t)o * 2 * kDo * a.hw + cell;
-    const float* qv = a.qv + (size_t)o * kDo * a.hw + cell;
+    float* __restrict__ out = a.out + (size_t)o * 2 * kDo * a.hw + cell;
+    const float* __restrict__ qv = a.qv + (size_t)o * kDo * a.hw + cell;
+#pragma unroll 4
     for (int dd = sl; dd < kCombCh; dd += 4) {
       const int d = d0 + dd;
-      const float* src = wo + ((size_t)qt * kDo + d) * kQT + qi;
-      const size_t sstride = (size_t)pl.nqt * kDo * kQT;
-      float acc0 = 0.0f, acc1 = 0.0f;
-      int s = 0;
-      for (; s + 1 < pl.nsplit; s += 2) {
-        acc0 += Wt[s][qi] * src[(size_t)s * sstride];
-        acc1 += Wt[s + 1][qi] * src[(size_t)(s + 1) * sstride];
-      }
-      if (s < pl.nsplit) acc0 += Wt[s][qi] * src[(size_t)s * sstride];
-      out[(size_t)d * a.hw] = acc0 + acc1;
+      out[(size_t)d * a.hw] = Tt[qi][dd];
       out[(size_t)(kDo + d) * a.hw] = qv[(size_t)d * a.hw];          // cat(mem, q_val), :163
     }
   } else {
     // mean-slot vector for this block's channels -> LDS, then broadcast to the masked cells
-    __shared__ float meanv[kCombCh];
     const int mq = pl.Mq & 63;
     if (tid < kCombCh) {
-      const int d = d0 + tid;
-      const float* src = wo + ((size_t)qt * kDo + d) * kQT + mq;
-      const size_t sstride = (size_t)pl.nqt * kDo * kQT;
+      const float* __restrict__ src = wo + ((size_t)qt * kQT + mq) * kDo + d0 + tid;
       float acc = 0.0f;
       for (int s = 0; s < pl.nsplit; ++s) acc += Wt[s][mq] * src[(size_t)s * sstride];
-      meanv[tid] = acc;
+      Tt[0][tid] = acc;
     }
     __syncthreads();
     const int cell = ((int)blockIdx.x - nqt_max) * kQT + qi;
     if (cell >= a.hw) return;
     const int cy = cell / a.w, cx = cell - cy * a.w;
     if (pl.qr.contains(cy, cx)) return;              // written by the query-tile blocks
-    float* out = a.out + (size_t)o * 2 * kDo * a.hw + cell;
-    const float* qv = a.qv + (size_t)o * kDo * a.hw + cell;
+    float* __restrict__ out = a.out + (size_t)o * 2 * kDo * a.hw + cell;
+    const float* __restrict__ qv = a.qv + (size_t)o * kDo * a.hw + cell;
+#pragma unroll 4
     for (int dd = sl; dd < kCombCh; dd += 4) {
       const int d = d0 + dd;
-      out[(size_t)d * a.hw] = meanv[dd];
+      out[(size_t)d * a.hw] = Tt[0][dd];
       out[(size_t)(kDo + d) * a.hw] = qv[(size_t)d * a.hw] * 0.0f;   // q_val * box (:358), x*0 semantics
     }
   }
@@ -572,6 +588,7 @@ int launch_memory_read(const MemReadArgs& m, hipStream_t st) {
     a.mk_cs = mk_cs; a.mk_os = mk_os; a.mv_cs = mv_cs; a.mv_os = mv_os;
     a.slots = slots_for(m.no, (int)hw);
     a.sqrt_de = sqrt_de;
+    a.bank_area = nullptr; a.bank_tcap = 0;
     a.ws_o = static_cast<float*>(m.ws);
     a.ws_ml = reinterpret_cast<float*>(static_cast<char*>(m.ws) +
                                        align256((size_t)m.no * a.slots * kDo * kQT * 4));
@@ -615,6 +632,46 @@ int launch_memory_read(const MemReadArgs& m, hipStream_t st) {
                        dim3(kThreads), 0, st, ga);
     if (int e = check_launch()) return e;
   }
+  return RMNET_OK;
+}
+
+size_t bank_read_ws_bytes(int no, int h, int w) {
+  const size_t slots = slots_for(no, h * w);
+  return align256((size_t)no * slots * kDo * kQT * 4) + align256((size_t)no * slots * 2 * kQT * 4);
+}
+
+int launch_bank_read(BankReadArgs& m, hipStream_t st) {
+  if (!m.bank || !m.qk || !m.qv || !m.out) return RMNET_E_INVALID_ARG;
+  if (m.no <= 0 || m.Tcap <= 0 || m.h <= 0 || m.w <= 0 || m.T <= 0 || m.T > m.Tcap)
+    return RMNET_E_INVALID_ARG;
+  if (m.no > 65535 || m.Tcap > kMaxT) return RMNET_E_UNSUPPORTED;
+  if (!m.ws || m.ws_bytes < bank_read_ws_bytes(m.no, m.h, m.w)) return RMNET_E_WORKSPACE;
+  const int hw = m.h * m.w;
+  m.slots = slots_for(m.no, hw);
+  m.ws_o = static_cast<float*>(m.ws);
+  m.ws_ml = reinterpret_cast<float*>(static_cast<char*>(m.ws) +
+                                     align256((size_t)m.no * m.slots * kDo * kQT * 4));
+  if (m.ev_start && hipEventRecord(m.ev_start, st) != hipSuccess) return RMNET_E_LAUNCH;
+  if (int e = launch_bank_main(m, st)) return e;
+  if (m.ev_mid && hipEventRecord(m.ev_mid, st) != hipSuccess) return RMNET_E_LAUNCH;
+  const BankView b = bank_view(const_cast<void*>(m.bank), m.no, m.Tcap, m.h, m.w);
+  KArgs a;
+  a.mk = a.mv = nullptr; a.qk = m.qk; a.qv = m.qv; a.out = m.out;
+  a.mem_rects = nullptr; a.qry_rects = m.qry_rects;
+  a.no = m.no; a.T = m.T; a.h = m.h; a.w = m.w; a.hw = hw;
+  a.mk_cs = a.mk_os = a.mv_cs = a.mv_os = 0;
+  a.slots = m.slots; a.sqrt_de = 0.0f;
+  a.bank_area = b.area; a.bank_tcap = m.Tcap;
+  a.ws_o = m.ws_o; a.ws_ml = m.ws_ml;
+  const int nqt_max = (hw + 1 + kQT - 1) / kQT;
+  const bool qreg = m.qry_rects != nullptr;
+  dim3 g2((unsigned)(nqt_max + (qreg ? (hw + kQT - 1) / kQT : 0)), kDo / kCombCh, m.no);
+  if (qreg)
+    hipLaunchKernelGGL(mr_combine<true>, g2, dim3(kThreads), 0, st, a, nqt_max);
+  else
+    hipLaunchKernelGGL(mr_combine<false>, g2, dim3(kThreads), 0, st, a, nqt_max);
+  if (int e = check_launch()) return e;
+  if (m.ev_end && hipEventRecord(m.ev_end, st) != hipSuccess) return RMNET_E_LAUNCH;
   return RMNET_OK;
 }
 

@@ -129,6 +129,70 @@ def memory_read(m_key, m_val, q_key, q_val, mem_rects=None, qry_rects=None, want
     return out, p
 
 
+class MemoryBank:
+    """Device-resident regional memory of one clip: ``no`` objects x ``capacity`` frame slots on an
+    h x w feature grid (csrc/bank.hip).  ``append`` writes a slot from the un-masked KeyValue outputs
+    and the frame's cell rectangles; ``read`` runs the fused regional read over the first T slots."""
+
+    def __init__(self, no, capacity, h, w, device):
+        lib = _lib.load()
+        self.no, self.capacity, self.h, self.w = int(no), int(capacity), int(h), int(w)
+        self.device = torch.device(device)
+        nb = lib.rmnet_bank_bytes(self.no, self.capacity, self.h, self.w)
+        if nb == 0:
+            raise RuntimeError('invalid bank geometry')
+        with torch.cuda.device(self.device):
+            self.blob = torch.zeros(nb, dtype=torch.uint8, device=self.device)
+        self.committed = 0
+
+    def append(self, slot, k4, v4, rects=None):
+        _check(k4, 'k4')
+        _check(v4, 'v4')
+        if tuple(k4.shape) != (self.no, 128, self.h, self.w) or tuple(v4.shape) != (self.no, 512, self.h, self.w):
+            raise RuntimeError('k4/v4 must be [no,128,h,w] / [no,512,h,w]')
+        if rects is not None:
+            _check(rects, 'rects', torch.int32)
+            if rects.numel() != self.no * 4:
+                raise RuntimeError('rects must be [no,4]')
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            rc = lib.rmnet_bank_append_f32(_ptr(self.blob), self.no, self.capacity, self.h, self.w, int(slot),
+                                           _ptr(k4), _ptr(v4), _ptr(rects), _stream(self.device))
+        _lib.check(rc, 'rmnet_bank_append_f32')
+
+    def stage(self, k4, v4, rects):
+        """Write one frame into the first free slot without committing it (the tentative previous
+        frame of models/rmnet.py:416-426).  Returns the number of frames visible to ``read``."""
+        if self.committed >= self.capacity:
+            raise RuntimeError('memory bank overflow (%d slots)' % self.capacity)
+        self.append(self.committed, k4, v4, rects)
+        return self.committed + 1
+
+    def commit(self):
+        self.committed += 1
+
+    def read(self, T, q_key, q_val, qry_rects=None, out=None, events=None):
+        _check(q_key, 'q_key')
+        _check(q_val, 'q_val')
+        if tuple(q_key.shape) != (self.no, 128, self.h, self.w) or tuple(q_val.shape) != (self.no, 512, self.h, self.w):
+            raise RuntimeError('q_key/q_val must be [no,128,h,w] / [no,512,h,w]')
+        if qry_rects is not None:
+            _check(qry_rects, 'qry_rects', torch.int32)
+        if not 1 <= int(T) <= self.capacity:
+            raise RuntimeError('T out of range')
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            if out is None:
+                out = torch.empty(self.no, 1024, self.h, self.w, dtype=torch.float32, device=self.device)
+            ws = _ws(lib.rmnet_bank_read_workspace_bytes(self.no, self.h, self.w), self.device)
+            ev = [ctypes.c_void_p(e) if e else None for e in (events or (None, None, None))]
+            rc = lib.rmnet_bank_read_f32(_ptr(self.blob), self.no, self.capacity, self.h, self.w, int(T),
+                                         _ptr(q_key), _ptr(q_val), _ptr(qry_rects), _ptr(out), _ptr(ws),
+                                         ws.numel(), _stream(self.device), ev[0], ev[1], ev[2])
+        _lib.check(rc, 'rmnet_bank_read_f32')
+        return out
+
+
 def rect_mask(x, rects):
     """x [n,C,T,h,w] * 0/1 cell rectangles [n,T,4] (models/rmnet.py:247-248, 357-358)."""
     _check(x, 'x')

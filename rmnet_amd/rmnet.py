@@ -56,33 +56,6 @@ class MemoryReader(nn.Module):
                                want_p=self.return_affinity, T=T)
 
 
-class _MemoryBank:
-    """Append-only per-object key/value memory in the kernel's layout (replaces the torch.cat at
-    models/rmnet.py:416-426 and the K-slot padding of :191-205)."""
-
-    def __init__(self, no, keydim, valdim, capacity, h, w, device):
-        self.keys = torch.zeros(no, keydim, capacity, h, w, device=device)
-        self.values = torch.zeros(no, valdim, capacity, h, w, device=device)
-        self.boxes = torch.zeros(no, capacity, 4, dtype=torch.int32, device=device)
-        self.rects = torch.zeros(no, capacity, 4, dtype=torch.int32, device=device)
-        self.committed = 0
-        self.capacity = capacity
-
-    def stage(self, k4, v4, boxes, rects):
-        """Write one frame into the first free slot without committing it."""
-        s = self.committed
-        if s >= self.capacity:
-            raise RuntimeError('memory bank overflow (%d slots)' % self.capacity)
-        self.keys[:, :, s] = k4
-        self.values[:, :, s] = v4
-        self.boxes[:, s] = boxes
-        self.rects[:, s] = rects
-        return s + 1          # frames visible to the read
-
-    def commit(self):
-        self.committed += 1
-
-
 class RMNet(nn.Module):
     def __init__(self, cfg=None):
         super().__init__()
@@ -211,8 +184,12 @@ class RMNet(nn.Module):
         else:
             k4e, v4e = k4.index_select(0, batch_of_obj), v4.index_select(0, batch_of_obj)
             r3e, r2e = r3.index_select(0, batch_of_obj), r2.index_select(0, batch_of_obj)
-        m4, _ = ops.memory_read(m_key, m_val, k4e.contiguous(), v4e.contiguous(), mem_rects, qry_rects, T=T,
-                                events=getattr(self, '_profile_events', None))
+        ev = getattr(self, '_profile_events', None)
+        if isinstance(m_key, ops.MemoryBank):       # the frame loop: pre-compacted split-fp16 bank
+            m4 = m_key.read(T, k4e.contiguous(), v4e.contiguous(), qry_rects, events=ev)
+        else:                                       # reference-layout fp32 tensors (public segment())
+            m4, _ = ops.memory_read(m_key, m_val, k4e.contiguous(), v4e.contiguous(), mem_rects, qry_rects,
+                                    T=T, events=ev)
         ps = F.softmax(self.decoder(m4, r3e, r2e), dim=1)[:, 1]
         logit = self.soft_aggregation(ps, K, n_objects)
         lw, uw, lh, uh = pad
@@ -248,8 +225,8 @@ class RMNet(nn.Module):
             self.device = device
 
     def new_bank(self, ctx, capacity):
-        return _MemoryBank(len(ctx.flat), self.kv_memory.key_conv.out_channels,
-                           self.kv_memory.value_conv.out_channels, capacity, ctx.h, ctx.w, ctx.device)
+        """Pre-allocated regional memory for one clip (replaces models/rmnet.py:191-205, 416-426)."""
+        return ops.MemoryBank(len(ctx.flat), capacity, ctx.h, ctx.w, ctx.device)
 
     def frame_step(self, ctx, bank, prev_frame, prev_mask, cur_frame, cur_flow, commit):
         """One iteration of models/rmnet.py:410-433: memorise frame t-1 (tentatively, or for good
@@ -257,16 +234,14 @@ class RMNet(nn.Module):
         frame t.  Returns the logits [B,K,H,W].  No host synchronisation."""
         B, K = ctx.B, ctx.K
         k4, v4, boxes, rects = self._encode_memory(prev_frame, prev_mask, ctx.n_max)
-        T = bank.stage(k4, v4, boxes.view(B * K, 4).index_select(0, ctx.flat),
-                       rects.view(B * K, 4).index_select(0, ctx.flat))
+        T = bank.stage(k4.contiguous(), v4.contiguous(), rects.view(B * K, 4).index_select(0, ctx.flat))
         if commit:
             bank.commit()
         expt = self.warp(prev_mask, cur_flow)[0]            # models/rmnet.py:429-431
         _, _, q_rects = ops.region_map(expt.contiguous(), want_map=False,
                                        cell_grid=(ctx.lw, ctx.lh, 16, ctx.h, ctx.w))
         q_rects = q_rects.view(B * K, 4).index_select(0, ctx.flat)
-        return self._segment_core(cur_frame, q_rects, bank.keys, bank.values,
-                                  bank.rects[:, :T].contiguous(), T, ctx.n_max, K, ctx.batch_of_obj)
+        return self._segment_core(cur_frame, q_rects, bank, None, None, T, ctx.n_max, K, ctx.batch_of_obj)
 
     def forward(self, frames, masks, optical_flows, n_objects, memorize_every, device=None):
         """models/rmnet.py:385-452.  frames [B,N,3,H,W] f32, masks [B,N,K,H,W] (one-hot, any int or

@@ -282,6 +282,91 @@ def test_memory_read_full_size_properties(no, T, h, w):
     assert torch.allclose(b[:, :512], 2.0 * a[:, :512] + 1.0, atol=1e-4, rtol=1e-4)
 
 
+def _fill_bank(ops, mk, mv, mr, capacity=None):
+    no, _, T, h, w = mk.shape
+    bank = ops.MemoryBank(no, capacity or T, h, w, dev())
+    for t in range(T):
+        rects = None if mr is None else cu(mr[:, t])
+        bank.append(t, cu(mk[:, :, t]), cu(mv[:, :, t]), rects)
+    return bank
+
+
+@pytest.mark.parametrize('no,T,h,w,regional', [
+    (1, 1, 4, 5, False), (2, 3, 9, 13, True), (3, 2, 12, 20, True), (1, 5, 30, 54, True),
+    (1, 4, 8, 8, True), (1, 7, 16, 24, False), (2, 9, 10, 7, True)])
+def test_bank_read_vs_oracle(no, T, h, w, regional, oracle_mod):
+    """The split-fp16 bank path (what the frame loop uses) against the oracle, same tolerance as the
+    fp32-MFMA path."""
+    from rmnet_amd import ops
+    rng = np.random.RandomState(no * 1000 + T * 100 + h + 1)
+    mk, mv, qk, qv, mr, qr = _random_case(rng, no, T, h, w, regional=regional)
+    bank = _fill_bank(ops, mk, mv, mr, capacity=T + 2)
+    if regional:
+        want, _ = oracle_mod.regional_memory_read(mk, mv, qk, qv, mr, qr)
+        got = bank.read(T, cu(qk), cu(qv), cu(qr))
+    else:
+        want, _ = oracle_mod.memory_read(mk, mv, qk, qv)
+        got = bank.read(T, cu(qk), cu(qv))
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL)
+
+
+def test_bank_edge_rectangles_overwrite_and_running_max(oracle_mod):
+    from rmnet_amd import ops
+    rng = np.random.RandomState(21)
+    h, w, T = 8, 16, 3
+    mk, mv, qk, qv, _, _ = _random_case(rng, 1, T, h, w, regional=False)
+    full, empty = (0, w - 1, 0, h - 1), (1, 0, 1, 0)
+    mk[:, :, 2, h - 1, w - 1] = qk[:, :, 2, 3] * 9.0       # late spike: forces the deferred max to bump
+    for mrect, qrect in [([empty] * 3, full), ([full] * 3, empty), ([full] * 3, full),
+                         ([empty, (3, 3, 2, 2), empty], (5, 5, 7, 7)), ([(0, 15, 0, 3), full, full], (0, 15, 0, 3)),
+                         ([(2, 9, 1, 6), empty, full], (1, 14, 0, 7))]:
+        mr, qr = np.array([mrect], np.int32), np.array([qrect], np.int32)
+        bank = _fill_bank(ops, mk, mv, mr)
+        want, _ = oracle_mod.regional_memory_read(mk, mv, qk, qv, mr, qr)
+        got = bank.read(T, cu(qk), cu(qv), cu(qr))
+        np.testing.assert_allclose(got.cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL, err_msg=str((mrect, qrect)))
+        # reading fewer frames ignores the later slots; overwriting a slot replaces it (tentative frame)
+        want2, _ = oracle_mod.regional_memory_read(mk[:, :, :2], mv[:, :, :2], qk, qv, mr[:, :2], qr)
+        np.testing.assert_allclose(bank.read(2, cu(qk), cu(qv), cu(qr)).cpu().numpy(), want2, atol=MR_ATOL, rtol=MR_RTOL)
+        bank.append(1, cu(mk[:, :, 0]), cu(mv[:, :, 0]), cu(mr[:, 0]))
+        mk3, mv3, mr3 = mk.copy(), mv.copy(), mr.copy()
+        mk3[:, :, 1], mv3[:, :, 1], mr3[:, 1] = mk[:, :, 0], mv[:, :, 0], mr[:, 0]
+        want3, _ = oracle_mod.regional_memory_read(mk3, mv3, qk, qv, mr3, qr)
+        np.testing.assert_allclose(bank.read(T, cu(qk), cu(qv), cu(qr)).cpu().numpy(), want3, atol=MR_ATOL, rtol=MR_RTOL)
+
+
+@pytest.mark.parametrize('no,T,h,w', [(1, 5, 30, 54), (3, 20, 45, 80)])
+def test_bank_full_size_agrees_with_fp32_kernel(no, T, h, w):
+    """BASELINE sizes: the split-fp16 bank read == the exact-fp32 MFMA read (two independent kernels,
+    different number formats and memory layouts) to fp32 rounding."""
+    from rmnet_amd import ops
+    rng = np.random.RandomState(T + 3)
+    g = torch.Generator(device='cpu').manual_seed(T)
+    mk = (torch.randn(no, 128, T, h, w, generator=g) * 0.6).to(dev())
+    mv = torch.randn(no, 512, T, h, w, generator=g).to(dev())
+    qk = (torch.randn(no, 128, h, w, generator=g) * 0.6).to(dev())
+    qv = torch.randn(no, 512, h, w, generator=g).to(dev())
+    mr = np.zeros((no, T, 4), np.int32)
+    qr = np.zeros((no, 4), np.int32)
+    for o in range(no):
+        for t in range(T):
+            x0, y0 = rng.randint(0, w // 2), rng.randint(0, h // 2)
+            mr[o, t] = (x0, x0 + w // 2, y0, y0 + h // 2)
+        x0, y0 = rng.randint(0, w // 3), rng.randint(0, h // 3)
+        qr[o] = (x0, x0 + w // 2, y0, y0 + h // 2)
+    bank = ops.MemoryBank(no, T, h, w, dev())
+    for t in range(T):
+        bank.append(t, mk[:, :, t].contiguous(), mv[:, :, t].contiguous(), cu(mr[:, t]))
+    got = bank.read(T, qk, qv, cu(qr))
+    want, _ = ops.memory_read(mk, mv, qk, qv, cu(mr), cu(qr))
+    assert torch.allclose(got, want, atol=MR_ATOL, rtol=MR_RTOL)
+    full = ops.MemoryBank(no, T, h, w, dev())
+    for t in range(T):
+        full.append(t, mk[:, :, t].contiguous(), torch.ones_like(mv[:, :, t]).contiguous())
+    ones = full.read(T, qk, qv)
+    assert torch.allclose(ones[:, :512], torch.ones_like(ones[:, :512]), atol=1e-5)   # soft-max rows sum to 1
+
+
 def test_rect_mask_vs_oracle(oracle_mod):
     from rmnet_amd import ops
     rng = np.random.RandomState(2)

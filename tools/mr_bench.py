@@ -46,6 +46,20 @@ def main():
         m = [ev.elapsed_ms(ev.ev[3 * i], ev.ev[3 * i + 1]) * 1e3 for i in range(a.reps)]
         c = [ev.elapsed_ms(ev.ev[3 * i + 1], ev.ev[3 * i + 2]) * 1e3 for i in range(a.reps)]
         floor = [ev.elapsed_ms(ev.ev[3 * i + 2], ev.ev[3 * i + 3]) * 1e3 for i in range(a.reps - 1)]
+        # split-fp16 bank path
+        bank = ops.MemoryBank(no, T, h, w, dev)
+        for t in range(T):
+            bank.append(t, mk[:, :, t].contiguous(), mv[:, :, t].contiguous(), None if mr is None else mr[:, t].contiguous())
+        for _ in range(5):
+            bank.read(T, qk, qv, qr)
+        torch.cuda.synchronize()
+        for i in range(a.reps):
+            bank.read(T, qk, qv, qr, events=tuple(ev.ev[3 * i:3 * i + 3]))
+        torch.cuda.synchronize()
+        bm = [ev.elapsed_ms(ev.ev[3 * i], ev.ev[3 * i + 1]) * 1e3 for i in range(a.reps)]
+        bc = [ev.elapsed_ms(ev.ev[3 * i + 1], ev.ev[3 * i + 2]) * 1e3 for i in range(a.reps)]
+        print('cfg%d frac=%-5s BANK  main avg %.2f min %.2f us | combine avg %.2f min %.2f us | %.0f GB/s (main)'
+              % (a.cfg, f, np.mean(bm), np.min(bm), np.mean(bc), np.min(bc), ab / np.mean(bm) / 1e3))
         print('cfg%d frac=%-5s main avg %.2f min %.2f us | combine avg %.2f min %.2f us | %.0f GB/s (main) | gap-to-next avg %.2f us'
               % (a.cfg, f, np.mean(m), np.min(m), np.mean(c), np.min(c), ab / np.mean(m) / 1e3, np.mean(floor)))
 
