@@ -10,9 +10,10 @@
 // read kernel's MFMA fragments want:
 //     keys    Kh, Kl : [slot][cell n][128 channels]   fp16 hi / lo planes (cell-major = the A operand
 //                      of S = K^T Q: 8 consecutive channels per lane, 16-byte loads)
-//     values  Vh, Vl : [slot][512 channels][cell n']  fp16 hi / lo planes (channel-major = the A
-//                      operand of O = V P), n' permuted inside every group of 32 cells so that the
-//                      8 cells a lane needs are contiguous (see kperm below)
+//     values  Vh, Vl : [slot][32-cell tile][32 channel tiles][64 lanes][8 cells] fp16 hi / lo planes:
+//                      exactly the A-fragment order of O = V P (lane = channel%16 + 16*group, the 8
+//                      cells of a group are those the S MFMA left in that lane group, see kperm), so a
+//                      wave's fragment load is ONE contiguous 1 KB block (8 full cache lines)
 //     area           : [slot] number of cells inside the box (cells beyond it, up to the next
 //                      multiple of 32, are zero padding)
 //   hi = fp16(x), lo = fp16(x - hi): x = hi + lo to 2^-22 relative, so
@@ -134,19 +135,21 @@ __global__ __launch_bounds__(kThreads) void bk_append(BankView b, int slot,
     *reinterpret_cast<half8*>(b.kl + off) = l0;
     *reinterpret_cast<half8*>(b.kl + off + 16) = l1;
   }
-  // values: gather [d][cell] -> split -> [d][perm(n)]
+  // values: gather [d][cell] -> split -> fragment order [tile u][d/16][lane][e]
   const float* vb = v4 + (size_t)o * kDo * b.hw + cell;
   const int pp = kperm(p);
-  _Float16* vh = reinterpret_cast<_Float16*>(b.vh) + (so * kDo) * b.hwp + (size_t)u * kJT + pp;
-  _Float16* vl = reinterpret_cast<_Float16*>(b.vl) + (so * kDo) * b.hwp + (size_t)u * kJT + pp;
+  const size_t vbase = (so * (b.hwp / kJT) + u) * (size_t)(kDo * kJT);   // halfs
+  _Float16* vh = reinterpret_cast<_Float16*>(b.vh) + vbase;
+  _Float16* vl = reinterpret_cast<_Float16*>(b.vl) + vbase;
 #pragma unroll 8
   for (int i = 0; i < kDo / 8; ++i) {
     const int d = rg + 8 * i;
     const float x = valid ? vb[(size_t)d * b.hw] : 0.0f;
     _Float16 hi, lo;
     split_f16(x, hi, lo);
-    vh[(size_t)d * b.hwp] = hi;
-    vl[(size_t)d * b.hwp] = lo;
+    const int idx = (((d >> 4) * 64) + (d & 15) + 16 * (pp >> 3)) * 8 + (pp & 7);
+    vh[idx] = hi;
+    vl[idx] = lo;
   }
 }
 
@@ -157,6 +160,7 @@ struct BArgs {
   const int32_t* qry_rects;  // [no][4] or null
   float* ws_o;               // [no][slots][kDo][kQT]
   float* ws_ml;              // [no][slots][2][kQT]
+  int32_t* ws_plan;          // [no][kPlanInts]
   int T, slots;
   float inv_sqrt_de;
 };
@@ -165,134 +169,113 @@ constexpr int kKbuf = kJT * kDe * 2;                       // bytes of one K pla
 constexpr int kLdsBytes = 4 * kKbuf                        // K hi/lo x 2 buffers
                           + 2 * 4 * 2 * 64 * 16            // P fragments [buf][ntile][hi/lo][lane] x 16 B
                           + 2 * kQT * 4                    // alpha [buf][64]
-                          + (kMaxT + 4) * 4;               // tile prefix
+                          + (kMaxT + 4) * 4                // tile prefix
+                          + kMaxT * 4;                     // cells per frame
 constexpr int kRThreads = 512;
+#ifndef BK_TRACE
+#define BK_TRACE 0     // experiments only: per-phase s_memtime stamps of block 0, waves 0 and 4
+#endif
 #ifndef BK_ABLATE
 #define BK_ABLATE 0   // experiments only: 1 = no V reloads, 2 = no PV MFMAs, 3 = no S/soft-max
 #endif                             // 8 waves = 2 per SIMD
 
 // Workgroup = 8 waves (2 per SIMD), 64 compacted queries x one split of the tile list.
 //   waves 0-3 ("producers", static priority 2): S = K^T Q for 16 queries each, online soft-max,
-//              P -> fp16 hi/lo fragments -> LDS; then their share of O += V P.
-//   waves 4-7 ("consumers"): only O += V P.
-//   Every wave owns 64 value channels (4 d-tiles x 4 query tiles = 64 accumulator registers) and
-//   streams its V A-fragments straight from the bank, one tile ahead.  Wave i and wave i+4 share a
-//   SIMD: because the producer has priority it runs PV(n) and S(n+1) first, and while it is busy
-//   with the soft-max VALU work of tile n+1 the consumer's PV(n) MFMAs fill the matrix pipe.
-__global__ __launch_bounds__(kRThreads, 2) void bk_main(const BArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
-  char* Kl_ = lds;                                 // [buf][plane][8 KB]
-  char* Pl_ = lds + 4 * kKbuf;                     // [buf][ntile][plane][lane*16]
-  float* Al = reinterpret_cast<float*>(Pl_ + 2 * 4 * 2 * 64 * 16);
-  int* tpre = reinterpret_cast<int*>(Al + 2 * kQT);
+//              P -> fp16 hi/lo fragments -> LDS; plus a SMALL share of O += V P (32 value channels).
+//   waves 4-7 ("consumers"): O += V P for 96 value channels each.
+//   Wave i and wave i+4 share a SIMD.  Between two barriers the producer runs PV(n) [24 MFMAs],
+//   S(n+1) [24 MFMAs] and the soft-max VALU work of tile n+1, the consumer runs PV(n) [72 MFMAs]:
+//   the matrix pipe sees 120 MFMAs per tile per SIMD and the producer's VALU phase hides under the
+//   consumer's MFMAs.  V A-fragments stream from the bank one tile ahead (1 KB contiguous per wave
+//   load); K tiles run two tiles ahead through registers into a double-buffered swizzled LDS tile.
+struct Walk {          // per-workgroup constants of the tile walk (all wave-uniform)
+  int jt0, ntl, qt, L, Mq;
+  Rect qr;
+  int t, lt;           // first tile
+};
 
+// One role of the workgroup.  PRODUCER: waves 0-3 (NDT = 2 d-tiles of PV + S + soft-max);
+// consumer: waves 4-7 (NDT = 6 d-tiles of PV).  Separate instantiations keep each role's register
+// set small (a shared body would keep the union of both alive: 268 spills).
+template <bool PRODUCER>
+__device__ inline void role_loop(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
+                                 const int* tpre, const int* tarea, int wave, int tid, long long t_entry) {
+  constexpr int NDT = PRODUCER ? 2 : 6;
   const BankView& b = a.b;
-  const int tid = threadIdx.x, o = blockIdx.y;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int o = blockIdx.y;
   const int lane = tid & 63, l15 = lane & 15, g = lane >> 4;
-  const bool producer = wave < 4;
-  if (producer) __builtin_amdgcn_s_setprio(2);
-
-  // ---- plan: tile prefix over the T memorised frames, query rectangle, split decode
-  if (tid < RMNET_WAVE) {
-    int carry = 0;
-    for (int base = 0; base < a.T; base += RMNET_WAVE) {
-      const int t = base + tid;
-      const int v = t < a.T ? (b.area[(size_t)o * b.Tcap + t] + kJT - 1) / kJT : 0;
-      int s = v;
-#pragma unroll
-      for (int d = 1; d < RMNET_WAVE; d <<= 1) {
-        const int up = __shfl_up(s, d);
-        if (tid >= d) s += up;
-      }
-      if (t < a.T) tpre[t + 1] = carry + s;
-      carry += __shfl(s, RMNET_WAVE - 1);
-    }
-    if (tid == 0) tpre[0] = 0;
-  }
-  __syncthreads();
-  const int njt = tpre[a.T];
-  Rect qr{0, b.w - 1, 0, b.h - 1};
-  if (a.qry_rects) {
-    const int32_t* q = a.qry_rects + (size_t)o * 4;
-    qr = Rect{max(q[0], 0), min(q[1], b.w - 1), max(q[2], 0), min(q[3], b.h - 1)};
-  }
-  const int Mq = qr.area();
-  const BankPlan pl = bank_plan(Mq, b.hw, njt, b.no, a.slots);
-  const int nact = pl.nqt * pl.nsplit;
-  if ((int)blockIdx.x >= nact) return;
-  int L;
-  {
-    const int q8 = nact >> 3, r8 = nact & 7, x = blockIdx.x & 7;   // XCD-contiguous logical ids
-    L = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (blockIdx.x >> 3);
-  }
-  const int s = L / pl.nqt, qt = L - s * pl.nqt;
-  const int jt0 = (int)(((long long)s * njt) / pl.nsplit);
-  const int jt1 = (int)(((long long)(s + 1) * njt) / pl.nsplit);
-
-  // Tile order: the walk may start at any tile of the split and wrap around (the online soft-max
-  // does not care).  Measured on MI355X: rotating the start by the query tile to spread L2 channel
-  // load is 4-20 % SLOWER (the workgroups of a split then stop sharing L2 lines in time), so the
-  // rotation is off; the wrap-around walk is kept because it costs nothing.
-  const int ntl = jt1 - jt0;
-  auto frame_of = [&](int j) {
-    int lo = 0, hi = a.T;
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (tpre[mid] <= j) lo = mid; else hi = mid;
-    }
-    return lo;
+  const int jt0 = wk.jt0, ntl = wk.ntl;
+  int t = wk.t, lt = wk.lt;
+  auto advance = [&](int& tt, int& ll, int j) {   // coordinates of global tile j (>= current)
+    while (tpre[tt + 1] <= j) ++tt;                // skips frames with an empty box
+    ll = j - tpre[tt];
   };
-  const int t_first = frame_of(jt0);
-  constexpr bool kRotate = false;
-  int jcur = jt0 + (kRotate ? (int)(((long long)qt * ntl) / pl.nqt) : 0);
-  int t = frame_of(jcur);
   const size_t so0 = (size_t)o * b.Tcap;
-  // K staging: the tile is one contiguous 8 KB block per plane; 512 threads x 16 B
+  const size_t tiles_per_slot = (size_t)(b.hwp / kJT);
+  // K: a tile is one contiguous 8 KB block per plane; 512 threads x 16 B.  LDS image: row = byte/256,
+  // chunk = (byte/16)&15 stored at chunk ^ (row & 15) -> conflict-free ds_read_b128 of the A fragments.
   half8 kr[2];
-  auto k_load = [&](int tt, int lt) {
-    const size_t off = ((so0 + tt) * b.hwp + (size_t)lt * kJT) * kDe * sizeof(_Float16) + (size_t)tid * 16;
+  auto k_load = [&](int tt, int ll) {
+    const size_t off = ((so0 + tt) * b.hwp + (size_t)ll * kJT) * kDe * sizeof(_Float16) + (size_t)tid * 16;
     kr[0] = *reinterpret_cast<const half8*>(b.kh + off);
     kr[1] = *reinterpret_cast<const half8*>(b.kl + off);
   };
+  const int krow = tid >> 4;
+  const int kdst = krow * 256 + (((tid & 15) ^ (krow & 15)) << 4);
   auto k_store = [&](int buf) {
-    // row = byte / 256, chunk = (byte / 16) & 15, stored at chunk ^ (row & 15): conflict-free b128 reads
-    const int row = tid >> 4, ch = tid & 15;
-    char* base = Kl_ + buf * 2 * kKbuf + row * 256 + ((ch ^ (row & 15)) << 4);
-    *reinterpret_cast<half8*>(base) = kr[0];
-    *reinterpret_cast<half8*>(base + kKbuf) = kr[1];
+    *reinterpret_cast<half8*>(Kl_ + buf * 2 * kKbuf + kdst) = kr[0];
+    *reinterpret_cast<half8*>(Kl_ + buf * 2 * kKbuf + kKbuf + kdst) = kr[1];
   };
-  // V fragments: lane (channel l15 of d-tile dt, group g) loads its 8 cells (16 B) of each plane
-  half8 vh[4], vl[4];
-  const size_t vrow = (size_t)(wave * 64 + l15) * b.hwp + 8 * g;
-  auto v_load = [&](int dt, int tt, int lt) {
-    const size_t off = (((so0 + tt) * kDo) * b.hwp + vrow + (size_t)dt * 16 * b.hwp + (size_t)lt * kJT) * sizeof(_Float16);
-    vh[dt] = *reinterpret_cast<const half8*>(b.vh + off);
-    vl[dt] = *reinterpret_cast<const half8*>(b.vl + off);
-  };
-
-  f32x4 acc[4][4];
+  // V: fragment-ordered planes; this wave's first d-tile and its lane inside a tile's 32 KB plane
+  const int dt0 = PRODUCER ? 2 * wave : 8 + 6 * (wave - 4);
+  const size_t vlane = (size_t)(dt0 * 64 + lane) * 16;
+  auto v_tile = [&](int tt, int ll) { return ((so0 + tt) * tiles_per_slot + ll) * (size_t)(kDo * kJT * 2) + vlane; };
+  half8 vh[NDT], vl[NDT];
+  f32x4 acc[NDT][4];
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
+  for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
     for (int it = 0; it < 4; ++it) acc[dt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
   float mref = -INFINITY, lsum = 0.0f;
+#if BK_TRACE
+  long long* trc = reinterpret_cast<long long*>(a.ws_o + ((size_t)o * a.slots + (a.slots - 1)) * (size_t)kDo * kQT) + (PRODUCER ? 0 : 1024);
+  int trn = 0;
+  const bool trace_on = blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0;
+#define STAMP() do { if (trace_on && trn < 1000) trc[trn++] = (long long)__builtin_readcyclecounter(); } while (0)
+  if (trace_on) trc[trn++] = t_entry;
+#else
+#define STAMP() do {} while (0)
+#endif
+  STAMP();
 
-  // ---- prologue: K and V loads of the first tile go out first, the scattered query loads behind
-  //      them, so the HBM latencies overlap
-  int lt = jcur - tpre[t];
+  // ---- prologue: K of the first two tiles and V of the first go out first, the scattered query
+  //      loads behind them: all their latencies overlap
+  int tn = t, ltn = lt;                            // tile n+1
+  half8 kr2[2] = {kr[0], kr[1]};
   k_load(t, lt);
+  if (ntl > 1) {
+    advance(tn, ltn, jt0 + 1);
+    const size_t off = ((so0 + tn) * b.hwp + (size_t)ltn * kJT) * kDe * sizeof(_Float16) + (size_t)tid * 16;
+    kr2[0] = *reinterpret_cast<const half8*>(b.kh + off);
+    kr2[1] = *reinterpret_cast<const half8*>(b.kl + off);
+  }
+  {
+    const size_t off = v_tile(t, lt);
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) v_load(dt, t, lt);
+    for (int dt = 0; dt < NDT; ++dt) {
+      vh[dt] = *reinterpret_cast<const half8*>(b.vh + off + dt * 1024);
+      vl[dt] = *reinterpret_cast<const half8*>(b.vl + off + dt * 1024);
+    }
+  }
   // query fragments (B operand of S): lane (query l15, group g) holds channels 32ks + 8g + e
-  half8 qh[4], ql[4];
-  if (producer) {
-    const int qn = qt * kQT + wave * 16 + l15;
-    const bool qvalid = qn < Mq;
+  half8 qh[PRODUCER ? 4 : 1], ql[PRODUCER ? 4 : 1];
+  if (PRODUCER) {
+    const int qn = wk.qt * kQT + wave * 16 + l15;
+    const bool qvalid = qn < wk.Mq;
     int cell = 0;
     if (qvalid) {
-      const int rw = qr.width(), ry = qn / rw;
-      cell = (qr.cy0 + ry) * b.w + qr.cx0 + (qn - ry * rw);
+      const int rw = wk.qr.width(), ry = qn / rw;
+      cell = (wk.qr.cy0 + ry) * b.w + wk.qr.cx0 + (qn - ry * rw);
     }
     const float* qb = a.qk + (size_t)o * kDe * b.hw + cell;
     const float keep = qvalid ? 1.0f : 0.0f;
@@ -303,27 +286,31 @@ __global__ __launch_bounds__(kRThreads, 2) void bk_main(const BArgs a) {
         const float x = qb[(size_t)(32 * ks + 8 * g + e) * b.hw] * keep;
         _Float16 hi, lo;
         split_f16(x, hi, lo);
-        qh[ks][e] = hi; ql[ks][e] = lo;
+        qh[PRODUCER ? ks : 0][e] = hi; ql[PRODUCER ? ks : 0][e] = lo;
       }
   }
   k_store(0);
+  if (ntl > 1) { kr[0] = kr2[0]; kr[1] = kr2[1]; k_store(1); }
   __syncthreads();
+  STAMP();
 
   for (int it_ = 0; it_ < ntl; ++it_) {
     const int buf = it_ & 1;
-    int jn = jcur + 1, tn = t, ltn = lt + 1;
+    STAMP();   // loop top
     const bool has_next = it_ + 1 < ntl;
-    if (has_next) {
-      if (jn == jt1) { jn = jt0; tn = t_first; }   // wrap around
-      while (tpre[tn + 1] <= jn) ++tn;             // skips frames with an empty box
-      ltn = jn - tpre[tn];
-      k_load(tn, ltn);
-    }
+    // K of tile n+2 is requested now and parked in LDS buffer `buf` at the END of this iteration
+    // (after the barrier nobody reads that buffer any more); it becomes visible with the barrier of
+    // iteration n+1 and is consumed in iteration n+2 -- its latency is never on the critical path.
+    const bool has_next2 = it_ + 2 < ntl;
+    int t2 = tn, lt2 = ltn;
+    if (has_next2) { advance(t2, lt2, jt0 + it_ + 2); k_load(t2, lt2); }
 
-    if (producer) {
-      const int nvalid = b.area[so0 + t] - lt * kJT;   // cells of this tile that exist (>= 1)
-      // ---- S = K^T Q (hi*hi + hi*lo + lo*hi), this wave's 16 queries x 32 cells
+    if (PRODUCER && BK_ABLATE != 3) {
+      const int nvalid = tarea[t] - lt * kJT;   // cells of this tile that exist (>= 1)
+      // ---- S = K^T Q (hi*hi + hi*lo + lo*hi), this wave's 16 queries x 32 cells.  Four independent
+      //      accumulator chains: two MFMAs on one accumulator are always >= 4 issues apart.
       f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+      f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
       const char* kb = Kl_ + buf * 2 * kKbuf;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {   // 8 fragment reads in flight, then their 12 MFMAs
@@ -338,15 +325,18 @@ __global__ __launch_bounds__(kRThreads, 2) void bk_main(const BArgs a) {
         }
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
-          const int ks = 2 * half + k2;
-          s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0l[k2], qh[ks], s0, 0, 0, 0);
-          s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l[k2], qh[ks], s1, 0, 0, 0);
-          s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h[k2], ql[ks], s0, 0, 0, 0);
-          s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h[k2], ql[ks], s1, 0, 0, 0);
+          const int ks = PRODUCER ? 2 * half + k2 : 0;
+          c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0l[k2], qh[ks], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l[k2], qh[ks], c1, 0, 0, 0);
           s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h[k2], qh[ks], s0, 0, 0, 0);
           s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h[k2], qh[ks], s1, 0, 0, 0);
+          c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h[k2], ql[ks], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h[k2], ql[ks], c1, 0, 0, 0);
         }
       }
+      s0 += c0;
+      s1 += c1;
+      STAMP();   // S done
       // lane holds S[cell 4g + r (+16)][query l15]; k index of the P fragment: e = r (+4)
       float sv[8];
       float tmax = -INFINITY;
@@ -367,11 +357,11 @@ __global__ __launch_bounds__(kRThreads, 2) void bk_main(const BArgs a) {
       half8 ph, plo;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float pv = __expf(sv[e] - mref);   // v_exp_f32: 1 ulp, one instruction
+        const float pv = __expf(sv[e] - mref);   // in [0, e^8]: no saturation needed for the split
         rs += pv;
-        _Float16 hi, lo;
-        split_f16(pv, hi, lo);
-        ph[e] = hi; plo[e] = lo;
+        const _Float16 hi = (_Float16)pv;
+        ph[e] = hi;
+        plo[e] = (_Float16)(pv - (float)hi);
       }
       rs += __shfl_xor(rs, 16);
       rs += __shfl_xor(rs, 32);
@@ -381,53 +371,152 @@ __global__ __launch_bounds__(kRThreads, 2) void bk_main(const BArgs a) {
       *reinterpret_cast<half8*>(pb + 1024) = plo;
       if (g == 0) Al[buf * kQT + wave * 16 + l15] = alpha;
     }
-    if (has_next) k_store(buf ^ 1);
-    __syncthreads();   // the one barrier per tile: P/alpha of this tile + K of the next are visible
+    STAMP();   // before barrier
+    __syncthreads();   // the one barrier per tile: P/alpha of this tile (+ K of tile n+1) are visible
+    STAMP();   // after barrier
 
-    // ---- O += V P for this wave's 64 value channels x 64 queries
-    half8 bh[4], bl[4];
-    float al[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const char* pb = Pl_ + ((buf * 4 + it) * 2) * 1024 + lane * 16;
-      bh[it] = *reinterpret_cast<const half8*>(pb);
-      bl[it] = *reinterpret_cast<const half8*>(pb + 1024);
-      al[it] = Al[buf * kQT + it * 16 + l15];
-    }
-    if (__any(al[0] != 1.0f || al[1] != 1.0f || al[2] != 1.0f || al[3] != 1.0f)) {
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) acc[dt][it] *= al[it];
-    }
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const half8 xh = vh[dt], xl = vl[dt];
+    // ---- O += V P for this wave's NDT d-tiles x 64 queries
+    {
+      const size_t noff = has_next ? v_tile(tn, ltn) : 0;
+      const char* nvh = b.vh + noff;
+      const char* nvl = b.vl + noff;
+      const char* pfr = Pl_ + (buf * 4) * 2048;
+      half8 bh[4], bl[4];
+      float al[4];
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
-        acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, bh[it], acc[dt][it], 0, 0, 0);
-        acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, bl[it], acc[dt][it], 0, 0, 0);
-        acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, bh[it], acc[dt][it], 0, 0, 0);
+        bh[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + lane * 16);
+        bl[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + 1024 + lane * 16);
+        al[it] = Al[buf * kQT + it * 16 + l15];
       }
-      if (has_next && BK_ABLATE != 1) v_load(dt, tn, ltn);   // refill for the next tile (a tile ahead)
+      if (__any(al[0] != 1.0f || al[1] != 1.0f || al[2] != 1.0f || al[3] != 1.0f)) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+          for (int it = 0; it < 4; ++it) acc[dt][it] *= al[it];
+      }
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const half8 xh = vh[dt], xl = vl[dt];
+#if BK_ABLATE == 2
+        asm volatile("" ::"v"(xh), "v"(xl));
+#else
+        // term-major order: the three MFMAs of one accumulator are 4 issues apart
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+          acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, bh[it], acc[dt][it], 0, 0, 0);
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+          acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, bl[it], acc[dt][it], 0, 0, 0);
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+          acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, bh[it], acc[dt][it], 0, 0, 0);
+#endif
+        if (has_next && BK_ABLATE != 1) {   // refill this fragment for the next tile (a tile ahead)
+          vh[dt] = *reinterpret_cast<const half8*>(nvh + dt * 1024);
+          vl[dt] = *reinterpret_cast<const half8*>(nvl + dt * 1024);
+        }
+      }
     }
-    jcur = jn;
-    t = tn;
-    lt = ltn;
+    STAMP();   // PV done
+    if (has_next2) k_store(buf);
+    t = tn; lt = ltn;
+    tn = t2; ltn = lt2;
   }
+  STAMP();
 
   // ---- partial (O, m, l) -> workspace slot L, layout [query][channel] (16-byte stores)
-  float* wo = a.ws_o + ((size_t)o * a.slots + L) * (size_t)kDo * kQT;
+  float* wo = a.ws_o + ((size_t)o * a.slots + wk.L) * (size_t)kDo * kQT;
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
+  for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
     for (int it = 0; it < 4; ++it)
-      *reinterpret_cast<f32x4*>(wo + (size_t)(it * 16 + l15) * kDo + wave * 64 + dt * 16 + 4 * g) = acc[dt][it];
-  if (producer && g == 0) {
-    float* wm = a.ws_ml + ((size_t)o * a.slots + L) * 2 * kQT;
+      *reinterpret_cast<f32x4*>(wo + (size_t)(it * 16 + l15) * kDo + (dt0 + dt) * 16 + 4 * g) = acc[dt][it];
+  if (PRODUCER && g == 0) {
+    float* wm = a.ws_ml + ((size_t)o * a.slots + wk.L) * 2 * kQT;
     wm[wave * 16 + l15] = mref;
     wm[kQT + wave * 16 + l15] = lsum;
   }
+#if BK_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  STAMP();   // epilogue stores drained
+}
+
+__global__ __launch_bounds__(kRThreads, 2) void bk_main(const BArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+  char* Kl_ = lds;                                 // [buf][plane][8 KB]
+  char* Pl_ = lds + 4 * kKbuf;                     // [buf][ntile][plane][lane*16]
+  float* Al = reinterpret_cast<float*>(Pl_ + 2 * 4 * 2 * 64 * 16);
+  int* tpre = reinterpret_cast<int*>(Al + 2 * kQT);
+  int* tarea = tpre + kMaxT + 4;
+
+  const long long t_entry = (long long)__builtin_readcyclecounter();
+  const BankView& b = a.b;
+  const int tid = threadIdx.x, o = blockIdx.y;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave < 4;
+  if (producer) __builtin_amdgcn_s_setprio(2);
+
+  // ---- plan: tile prefix over the T memorised frames, query rectangle, split decode.  The query
+  //      rectangle load is issued first so that its latency overlaps the area loads.
+  int q0 = 0, q1 = b.w - 1, q2 = 0, q3 = b.h - 1;
+  if (a.qry_rects) {
+    const int32_t* q = a.qry_rects + (size_t)o * 4;
+    q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+  }
+  if (tid < RMNET_WAVE) {
+    int carry = 0;
+    for (int base = 0; base < a.T; base += RMNET_WAVE) {
+      const int t = base + tid;
+      const int ar = t < a.T ? b.area[(size_t)o * b.Tcap + t] : 0;
+      int s = (ar + kJT - 1) / kJT;
+#pragma unroll
+      for (int d = 1; d < RMNET_WAVE; d <<= 1) {
+        const int up = __shfl_up(s, d);
+        if (tid >= d) s += up;
+      }
+      if (t < a.T) { tpre[t + 1] = carry + s; tarea[t] = ar; }
+      carry += __shfl(s, RMNET_WAVE - 1);
+    }
+    if (tid == 0) tpre[0] = 0;
+  }
+  __syncthreads();
+  const int njt = tpre[a.T];
+  Walk wk;
+  wk.qr = Rect{max(q0, 0), min(q1, b.w - 1), max(q2, 0), min(q3, b.h - 1)};
+  wk.Mq = wk.qr.area();
+  const BankPlan pl = bank_plan(wk.Mq, b.hw, njt, b.no, a.slots);
+  const int nact = pl.nqt * pl.nsplit;
+  if (blockIdx.x == 0 && tid == 0) {   // plan record for the combine kernel
+    int m = 0;
+    for (int t = 0; t < a.T; ++t) m += tarea[t];
+    int32_t* pr = a.ws_plan + (size_t)o * kPlanInts;
+    pr[0] = wk.Mq; pr[1] = pl.nqt; pr[2] = pl.nsplit; pr[3] = m;
+    pr[4] = wk.qr.cx0; pr[5] = wk.qr.cx1; pr[6] = wk.qr.cy0; pr[7] = wk.qr.cy1;
+  }
+  if ((int)blockIdx.x >= nact) return;
+  {
+    const int q8 = nact >> 3, r8 = nact & 7, x = blockIdx.x & 7;   // XCD-contiguous logical ids
+    wk.L = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (blockIdx.x >> 3);
+  }
+  const int s = wk.L / pl.nqt;
+  wk.qt = wk.L - s * pl.nqt;
+  wk.jt0 = (int)(((long long)s * njt) / pl.nsplit);
+  wk.ntl = (int)(((long long)(s + 1) * njt) / pl.nsplit) - wk.jt0;
+  {
+    int lo = 0, hi = a.T;   // frame of the first tile
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (tpre[mid] <= wk.jt0) lo = mid; else hi = mid;
+    }
+    wk.t = lo;
+    wk.lt = wk.jt0 - tpre[lo];
+  }
+  if (producer)
+    role_loop<true>(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, tid, t_entry);
+  else
+    role_loop<false>(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, tid, t_entry);
 }
 
 }  // namespace
@@ -446,7 +535,7 @@ int launch_bank_main(const BankReadArgs& m, hipStream_t st) {
   BArgs a;
   a.b = bank_view(const_cast<void*>(m.bank), m.no, m.Tcap, m.h, m.w);
   a.qk = m.qk; a.qv = m.qv; a.qry_rects = m.qry_rects;
-  a.ws_o = m.ws_o; a.ws_ml = m.ws_ml;
+  a.ws_o = m.ws_o; a.ws_ml = m.ws_ml; a.ws_plan = m.ws_plan;
   a.T = m.T; a.slots = m.slots;
   a.inv_sqrt_de = 1.0f / sqrtf((float)kDe);
   hipLaunchKernelGGL(bk_main, dim3(m.slots, m.no), dim3(kRThreads), 0, st, a);

@@ -99,7 +99,7 @@ int rmnet_bank_read_f32(const void* bank, int no, int Tcap, int h, int w, int T,
   BankReadArgs a;
   a.bank = bank; a.no = no; a.Tcap = Tcap; a.h = h; a.w = w; a.T = T;
   a.qk = q_key; a.qv = q_val; a.qry_rects = qry_rects; a.out = mem_val;
-  a.ws_o = nullptr; a.ws_ml = nullptr; a.slots = 0;
+  a.ws_o = nullptr; a.ws_ml = nullptr; a.ws_plan = nullptr; a.slots = 0;
   a.ws = workspace; a.ws_bytes = workspace_bytes;
   a.ev_start = static_cast<hipEvent_t>(ev_start);
   a.ev_mid = static_cast<hipEvent_t>(ev_mid);

@@ -94,7 +94,7 @@ size_t bank_bytes(int no, int Tcap, int h, int w);
 
 // Split heuristic shared by the read kernels and the combine kernel (must agree exactly).
 constexpr int kSplitTargetSlots = 256;   // workgroups per launch to aim for (one per CU)
-constexpr int kSplitMinTiles = 4;        // a split must amortise its prologue + 128 KB partial
+constexpr int kSplitMinTiles = 2;        // a split must amortise its prologue + 128 KB partial
 constexpr int kSplitMax = 64;
 struct BankPlan { int nqt, nsplit; };
 __host__ __device__ inline BankPlan bank_plan(int Mq, int hw, int njt, int no, int slots) {
@@ -111,6 +111,10 @@ __host__ __device__ inline BankPlan bank_plan(int Mq, int hw, int njt, int no, i
   return p;
 }
 
+// Plan record written by block 0 of a read kernel for the combine kernel (one 32-byte load instead of
+// re-deriving the plan from rectangles / areas): {Mq, nqt, nsplit, M, qr.cx0, qr.cx1, qr.cy0, qr.cy1}.
+constexpr int kPlanInts = 8;
+
 struct BankReadArgs {
   const void* bank;
   int no, Tcap, h, w, T;
@@ -118,6 +122,7 @@ struct BankReadArgs {
   const int32_t* qry_rects;
   float* out;
   float *ws_o, *ws_ml;
+  int32_t* ws_plan;
   int slots;
   void* ws;
   size_t ws_bytes;

@@ -67,6 +67,7 @@ struct KArgs {
   const int32_t* qry_rects;  // [no][4] or null
   float* ws_o;               // [no][slots][kDo][kQT]
   float* ws_ml;              // [no][slots][2][kQT]
+  int32_t* ws_plan;          // [no][kPlanInts], written by block 0 of the read kernel
   int no, T, h, w, hw;
   long long mk_cs, mk_os, mv_cs, mv_os;
   int slots;                 // workgroup slots per object (grid.x of mr_main)
@@ -192,6 +193,11 @@ __global__ __launch_bounds__(kThreads, 1) void mr_main(const KArgs a) {
   if (tid < 2) flags[tid] = 0;
   const Plan pl = make_plan<REGIONAL>(a, o, prefix);
   const int nact = pl.nqt * pl.nsplit;
+  if (blockIdx.x == 0 && tid == 0) {   // plan record for the combine kernel
+    int32_t* pr = a.ws_plan + (size_t)o * kPlanInts;
+    pr[0] = pl.Mq; pr[1] = pl.nqt; pr[2] = pl.nsplit; pr[3] = pl.M;
+    pr[4] = pl.qr.cx0; pr[5] = pl.qr.cx1; pr[6] = pl.qr.cy0; pr[7] = pl.qr.cy1;
+  }
   if ((int)blockIdx.x >= nact) return;
   const int L = xcd_remap(blockIdx.x, nact);
   const int s = L / pl.nqt, qt = L - s * pl.nqt;
@@ -337,16 +343,17 @@ __global__ __launch_bounds__(kThreads, 1) void mr_main(const KArgs a) {
   }
 }
 
-constexpr int kCombCh = 64;  // read-out channels (and as many q_val channels) per combine block
+constexpr int kCombCh = 16;  // read-out channels (and as many q_val channels) per combine block
 
 // Merge the per-split partials (workspace layout [slot][query][channel]).
-// grid = (nqt_max + cell tiles, kDo / kCombCh, no):
-//   blocks [0, nqt_max)   : one compacted query tile x 64 channels each (exit beyond the live tiles).
-//        The split weights w[s][q] = exp(m_s - m_tot) / l_tot are built by 4 lanes per query; then
-//        thread (channel, query group) accumulates 16 queries x nsplit partial values with fully
-//        independent, coalesced 256-byte loads, the 64x64 tile is transposed through LDS and
-//        scattered to the queries' cells (coalesced along cells) with the q_val half of the cat
-//        (models/rmnet.py:163).
+// grid = (nqt_max + cell tiles, kDo / kCombCh, no).  The plan comes from the 32-byte record the read
+// kernel left behind (one load instead of re-deriving it).
+//   blocks [0, nqt_max)   : one compacted query tile x 16 channels each (exit beyond the live tiles):
+//        4 lanes per query build the split weights w[s][q] = exp(m_s - m_tot) / l_tot (with the
+//        closed-form N_out * exp(-m_tot) term of the masked memory cells); then thread
+//        (channel, query group) accumulates 4 queries x nsplit partials with 32 independent loads in
+//        flight, the 64 x 16 tile goes through LDS and is written to the queries' cells coalesced
+//        along cells, together with the q_val half of the cat (models/rmnet.py:163).
 //   blocks [nqt_max, ...) : one tile of 64 grid cells each; cells OUTSIDE the query box get the
 //        mean-slot vector (uniform soft-max, see file header) and q_val * 0.  Skipped when dense.
 template <bool REGIONAL>
@@ -354,9 +361,14 @@ __global__ __launch_bounds__(kThreads) void mr_combine(const KArgs a, int nqt_ma
   __shared__ float Wt[kMaxSplits][kQT];
   __shared__ float red[4][kQT];
   __shared__ float Tt[kQT][kCombCh + 1];
-  __shared__ int prefix[kMaxT + 4];
   const int tid = threadIdx.x, o = blockIdx.z;
-  const Plan pl = make_plan<REGIONAL>(a, o, prefix);
+  Plan pl;
+  {
+    const int32_t* pr = a.ws_plan + (size_t)o * kPlanInts;
+    pl.Mq = pr[0]; pl.nqt = pr[1]; pl.nsplit = pr[2]; pl.M = pr[3];
+    pl.qr = Rect{pr[4], pr[5], pr[6], pr[7]};
+    pl.njt = 0;
+  }
   const int qi = tid & 63, sl = tid >> 6;
   const float n_out = (float)(a.T * a.hw - pl.M);
   const float* __restrict__ ml = a.ws_ml + (size_t)o * a.slots * 2 * kQT;
@@ -392,19 +404,29 @@ __global__ __launch_bounds__(kThreads) void mr_combine(const KArgs a, int nqt_ma
   const int d0 = blockIdx.y * kCombCh;
   const size_t sstride = (size_t)pl.nqt * kDo * kQT;   // between the splits of one query tile
   if (!fill) {
-    {  // accumulate: thread = (channel di, query group qs), queries qs + 4k
-      const int di = tid & 63, qs = tid >> 6;
-      float acc[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
+    {  // accumulate: thread = (channel di, query group qs), queries qs + 16k
+      const int di = tid & 15, qs = tid >> 4;
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
       const float* __restrict__ src = wo + (size_t)qt * kDo * kQT + d0 + di;
-      for (int s = 0; s < pl.nsplit; ++s) {
+      int s = 0;
+      for (; s + 8 <= pl.nsplit; s += 8) {   // 32 independent loads in flight per thread
+        float v[8][4];
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
-          acc[k] += Wt[s][qs + 4 * k] * src[(size_t)s * sstride + (size_t)(qs + 4 * k) * kDo];
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[u][k] = src[(size_t)(s + u) * sstride + (size_t)(qs + 16 * k) * kDo];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[k] += Wt[s + u][qs + 16 * k] * v[u][k];
+      }
+      for (; s < pl.nsplit; ++s) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          acc[k] += Wt[s][qs + 16 * k] * src[(size_t)s * sstride + (size_t)(qs + 16 * k) * kDo];
       }
 #pragma unroll
-      for (int k = 0; k < 16; ++k) Tt[qs + 4 * k][di] = acc[k];
+      for (int k = 0; k < 4; ++k) Tt[qs + 16 * k][di] = acc[k];
     }
     __syncthreads();
     const int n = qt * kQT + qi;
@@ -412,7 +434,7 @@ __global__ __launch_bounds__(kThreads) void mr_combine(const KArgs a, int nqt_ma
     const int cell = REGIONAL ? query_cell(pl, a.w, n) : n;
     float* __restrict__ out = a.out + (size_t)o * 2 * kDo * a.hw + cell;
     const float* __restrict__ qv = a.qv + (size_t)o * kDo * a.hw + cell;
-#pragma unroll 4
+#pragma unroll
     for (int dd = sl; dd < kCombCh; dd += 4) {
       const int d = d0 + dd;
       out[(size_t)d * a.hw] = Tt[qi][dd];
@@ -434,7 +456,7 @@ __global__ __launch_bounds__(kThreads) void mr_combine(const KArgs a, int nqt_ma
     if (pl.qr.contains(cy, cx)) return;              // written by the query-tile blocks
     float* __restrict__ out = a.out + (size_t)o * 2 * kDo * a.hw + cell;
     const float* __restrict__ qv = a.qv + (size_t)o * kDo * a.hw + cell;
-#pragma unroll 4
+#pragma unroll
     for (int dd = sl; dd < kCombCh; dd += 4) {
       const int d = d0 + dd;
       out[(size_t)d * a.hw] = Tt[0][dd];
@@ -559,7 +581,8 @@ size_t memory_read_ws_bytes(int no, int De, int Do, int T, int h, int w, int fla
   const size_t hw = (size_t)h * w;
   if (fast_shape(De, Do, T, flags)) {
     const size_t slots = slots_for(no, (int)hw);
-    return align256((size_t)no * slots * kDo * kQT * 4) + align256((size_t)no * slots * 2 * kQT * 4);
+    return align256((size_t)no * slots * kDo * kQT * 4) + align256((size_t)no * slots * 2 * kQT * 4) +
+           align256((size_t)no * kPlanInts * 4);
   }
   return align256((size_t)no * T * hw * hw * 4);  // a p-sized buffer
 }
@@ -592,6 +615,8 @@ int launch_memory_read(const MemReadArgs& m, hipStream_t st) {
     a.ws_o = static_cast<float*>(m.ws);
     a.ws_ml = reinterpret_cast<float*>(static_cast<char*>(m.ws) +
                                        align256((size_t)m.no * a.slots * kDo * kQT * 4));
+    a.ws_plan = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.ws_ml) +
+                                           align256((size_t)m.no * a.slots * 2 * kQT * 4));
     const int nqt_max = (int)((hw + 1 + kQT - 1) / kQT);
     dim3 g1(a.slots, m.no);
     dim3 g2((unsigned)(nqt_max + (regional ? (hw + kQT - 1) / kQT : 0)), kDo / kCombCh, m.no);
@@ -637,7 +662,8 @@ int launch_memory_read(const MemReadArgs& m, hipStream_t st) {
 
 size_t bank_read_ws_bytes(int no, int h, int w) {
   const size_t slots = slots_for(no, h * w);
-  return align256((size_t)no * slots * kDo * kQT * 4) + align256((size_t)no * slots * 2 * kQT * 4);
+  return align256((size_t)no * slots * kDo * kQT * 4) + align256((size_t)no * slots * 2 * kQT * 4) +
+         align256((size_t)no * kPlanInts * 4);
 }
 
 int launch_bank_read(BankReadArgs& m, hipStream_t st) {
@@ -651,6 +677,8 @@ int launch_bank_read(BankReadArgs& m, hipStream_t st) {
   m.ws_o = static_cast<float*>(m.ws);
   m.ws_ml = reinterpret_cast<float*>(static_cast<char*>(m.ws) +
                                      align256((size_t)m.no * m.slots * kDo * kQT * 4));
+  m.ws_plan = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(m.ws_ml) +
+                                         align256((size_t)m.no * m.slots * 2 * kQT * 4));
   if (m.ev_start && hipEventRecord(m.ev_start, st) != hipSuccess) return RMNET_E_LAUNCH;
   if (int e = launch_bank_main(m, st)) return e;
   if (m.ev_mid && hipEventRecord(m.ev_mid, st) != hipSuccess) return RMNET_E_LAUNCH;
@@ -662,7 +690,7 @@ int launch_bank_read(BankReadArgs& m, hipStream_t st) {
   a.mk_cs = a.mk_os = a.mv_cs = a.mv_os = 0;
   a.slots = m.slots; a.sqrt_de = 0.0f;
   a.bank_area = b.area; a.bank_tcap = m.Tcap;
-  a.ws_o = m.ws_o; a.ws_ml = m.ws_ml;
+  a.ws_o = m.ws_o; a.ws_ml = m.ws_ml; a.ws_plan = m.ws_plan;
   const int nqt_max = (hw + 1 + kQT - 1) / kQT;
   const bool qreg = m.qry_rects != nullptr;
   dim3 g2((unsigned)(nqt_max + (qreg ? (hw + kQT - 1) / kQT : 0)), kDo / kCombCh, m.no);

@@ -171,7 +171,7 @@ class MemoryBank:
     def commit(self):
         self.committed += 1
 
-    def read(self, T, q_key, q_val, qry_rects=None, out=None, events=None):
+    def read(self, T, q_key, q_val, qry_rects=None, out=None, events=None, ws=None):
         _check(q_key, 'q_key')
         _check(q_val, 'q_val')
         if tuple(q_key.shape) != (self.no, 128, self.h, self.w) or tuple(q_val.shape) != (self.no, 512, self.h, self.w):
@@ -184,7 +184,8 @@ class MemoryBank:
         with torch.cuda.device(self.device):
             if out is None:
                 out = torch.empty(self.no, 1024, self.h, self.w, dtype=torch.float32, device=self.device)
-            ws = _ws(lib.rmnet_bank_read_workspace_bytes(self.no, self.h, self.w), self.device)
+            if ws is None:
+                ws = _ws(lib.rmnet_bank_read_workspace_bytes(self.no, self.h, self.w), self.device)
             ev = [ctypes.c_void_p(e) if e else None for e in (events or (None, None, None))]
             rc = lib.rmnet_bank_read_f32(_ptr(self.blob), self.no, self.capacity, self.h, self.w, int(T),
                                          _ptr(q_key), _ptr(q_val), _ptr(qry_rects), _ptr(out), _ptr(ws),

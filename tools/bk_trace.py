@@ -1,0 +1,41 @@
+# -*- coding: utf-8 -*-
+"""Per-phase cycle stamps of bk_main (needs a library built with -DBK_TRACE=1)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from rmnet_amd import ops, _lib
+no, T, h, w = 1, 5, 30, 54
+dev = torch.device('cuda', 0)
+g = torch.Generator().manual_seed(0)
+mk = (torch.randn(no, 128, T, h, w, generator=g) * 0.6).to(dev)
+mv = torch.randn(no, 512, T, h, w, generator=g).to(dev)
+qk = (torch.randn(no, 128, h, w, generator=g) * 0.6).to(dev)
+qv = torch.randn(no, 512, h, w, generator=g).to(dev)
+frac = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+rh, rw = max(1, int(round(h * frac ** 0.5))), max(1, int(round(w * frac ** 0.5)))
+y0, x0 = (h - rh) // 2, (w - rw) // 2
+rect = torch.tensor([[x0, x0 + rw - 1, y0, y0 + rh - 1]] * no, dtype=torch.int32, device=dev)
+bank = ops.MemoryBank(no, T, h, w, dev)
+for t in range(T):
+    bank.append(t, mk[:, :, t].contiguous(), mv[:, :, t].contiguous(), rect)
+lib = _lib.load()
+nb = lib.rmnet_bank_read_workspace_bytes(no, h, w)
+ws = torch.zeros(nb, dtype=torch.uint8, device=dev)
+for _ in range(3):
+    bank.read(T, qk, qv, rect, ws=ws)
+torch.cuda.synchronize()
+slots = 256
+off = (slots - 1) * 512 * 64 * 4
+tr = ws[off:off + 2048 * 8].view(torch.int64).cpu().numpy()
+for name, a in (('producer wave0', tr[:1024]), ('consumer wave4', tr[1024:2048])):
+    a = a[a != 0]
+    d = np.diff(a)
+    print(name, 'n stamps', len(a), 'total', a[-1] - a[0])
+    print('  all deltas' if len(d) < 40 else '  first 12 deltas', d[:40] if len(d) < 40 else d[:12])
+    per = 5 if 'producer' in name else 4
+    nfull = min(20, (len(d) - 4) // per)
+    if nfull < 1:
+        continue
+    body = d[3:3 + per * nfull].reshape(-1, per)
+    print('  labels:', ['top->S done', 'softmax->pre-barrier', 'barrier', 'PV', '->next top'] if per == 5 else ['top->pre-barrier', 'barrier', 'PV', '->next top'])
+    print('  per-iteration deltas (mean over its):', body.mean(0).round(0), 'sum', body.mean(0).sum())
