@@ -6,9 +6,11 @@ one-hot masks u8 [1,N,K,H,W], flows f32 [1,N,2,H,W], n_objects i64 [1,N]."""
 import torch
 
 
-def synthetic_clip(N, K, H, W, seed=0):
+def synthetic_clip(N, K, H, W, seed=0, size=1.0):
     """Moving-blob clip: frames f32 [1,N,3,H,W], one-hot masks u8 [1,N,K,H,W], constant-drift
-    flows f32 [1,N,2,H,W], n_objects i64 [1,N]."""
+    flows f32 [1,N,2,H,W], n_objects i64 [1,N].  ``size`` scales the blob radii: 1.0 gives small
+    objects (~4 % of the frame, used by the golden fixtures); 2.1 gives ~18 % of the frame, the object
+    size SURVEY.md section 8d asks for in the fps workload (box + 128 px covers 35-55 % of 480p)."""
     g = torch.Generator().manual_seed(seed)
     ys = torch.arange(H).view(H, 1).float()
     xs = torch.arange(W).view(1, W).float()
@@ -22,7 +24,7 @@ def synthetic_clip(N, K, H, W, seed=0):
         for o in range(1, K):
             cy = H * (0.25 + 0.5 * ((o * 37) % 100) / 100.0) + 2.0 * t
             cx = W * (0.2 + 0.6 * ((o * 61) % 100) / 100.0) + 3.0 * t
-            ry, rx = H * (0.10 + 0.03 * o), W * (0.08 + 0.02 * o)
+            ry, rx = H * (0.10 + 0.03 * o) * size, W * (0.08 + 0.02 * o) * size
             inside = ((ys - cy) / ry) ** 2 + ((xs - cx) / rx) ** 2 <= 1.0
             label[inside] = o
             img = img + inside.float() * torch.tensor([0.8, -0.5, 0.3]).view(3, 1, 1) * (1.0 if o % 2 else -1.0)
