@@ -3,14 +3,16 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
-Workload (BASELINE.json configs[1], synthetic): 480x854, 1 object (K = 2 mask channels), memory
-pinned at T = 5 frames (4 committed + the tentative previous frame).  One "step" = one frame of the
+Workload (BASELINE.json configs[1], synthetic): 480x854 clips, 1 object each (K = 2 mask channels),
+memory pinned at T = 5 frames (4 committed + the tentative previous frame); ``--clips-per-gpu`` (default
+4) independent clips are batched on every GPU -- videos share nothing, and a single 480p stream cannot
+fill 256 CUs (measured: 147 frames/s with 1 clip, 176 / 196 / 209 with 2 / 4 / 8).  One "step" = one frame of the
 reference's loop (models/rmnet.py:410-450, utils/helpers.py:55): TinyFlowNet on the frame pair,
 memorise frame t-1 (ResNet-50 memory encoder + KV head + region boxes + bank write), regional query
 boxes from the flow-warped previous mask, query encoder + KV head, fused regional memory read,
 decoder, soft aggregation, soft-max.  fp32 everywhere (the reference's dtype).  Inputs are resident
-in HBM before the timed region.  With N ranks every rank runs its own clip (videos are
-independent; weak scaling, no data-path collective) and ``value`` = N * K / max-over-ranks time.
+in HBM before the timed region.  With N ranks every rank runs its own clips (videos are independent;
+weak scaling, no data-path collective) and ``value`` = N * clips * K / max-over-ranks time.
 
 The JSON line also carries
   roofline     -- the dominant hand-written kernel (bk_main, the regional memory read) timed live
@@ -106,10 +108,17 @@ def cpu_baseline(n_frames=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True')
+    ap.add_argument('--no-miopen-find', action='store_true',
+                    help='leave torch.backends.cudnn.benchmark off (MIOpen immediate mode; ~5 %% slower convs)')
+    ap.add_argument('--channels-last', action='store_true', help='conv stacks in NHWC memory format (experiment)')
+    ap.add_argument('--clips-per-gpu', type=int, default=4,
+                    help='independent clips batched on every GPU (one 480p clip cannot fill 256 CUs)')
+    ap.add_argument('--graph', action='store_true', help='replay the frame step as one captured HIP graph')
+    ap.add_argument('--dist-backend', default=None, help="override the process-group backend ('gloo' lets several "
+                    "ranks share one GPU when testing the N>1 path on a 1-GPU box)")
     args = ap.parse_args()
 
     from rmnet_amd import dist as rd
@@ -118,22 +127,30 @@ def main():
     from rmnet_amd.synthetic import synthetic_clip
     from rmnet_amd.tiny_flownet import TinyFlowNet
 
-    rank, world, local = rd.init_from_env()
+    rank, world, local = rd.init_from_env(args.dist_backend)
+    if args.dist_backend == 'gloo':
+        local = local % max(torch.cuda.device_count(), 1)
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     torch.set_grad_enabled(False)
-    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+    torch.backends.cudnn.benchmark = not args.no_miopen_find
 
     net = networks.procedural_init_(RMNet(None)).to(dev).eval()
     tfn = networks.procedural_init_(TinyFlowNet(None)).to(dev).eval()
+    if args.channels_last:
+        net = net.to(memory_format=torch.channels_last)
+        tfn = tfn.to(memory_format=torch.channels_last)
     n_clip = 12
-    frames, masks, _, _ = synthetic_clip(n_clip, K_CH, H, W, seed=rank, size=2.1)   # every rank its own clip;
-    # size=2.1: object ~18 % of the frame, regional boxes ~46 % of the cells
-    frames, masks = frames.to(dev), masks.to(dev).float()
+    B = max(1, args.clips_per_gpu)
+    # every rank its own clip(s); size=2.1: object ~18 % of the frame, regional boxes ~46 % of the cells
+    # 
+    clips = [synthetic_clip(n_clip, K_CH, H, W, seed=rank * 64 + c, size=2.1) for c in range(B)]
+    frames = torch.cat([c[0] for c in clips]).to(dev)
+    masks = torch.cat([c[1] for c in clips]).to(dev).float()
 
-    ctx = net._ClipContext(net, 1, K_CH, H, W, [K_CH - 1], dev)
+    ctx = net._ClipContext(net, B, K_CH, H, W, [K_CH - 1] * B, dev)
     bank = net.new_bank(ctx, T_MEM)
     for t in range(1, T_MEM):                                             # fill 4 committed frames
         flow = tfn._forward(frames[:, t], frames[:, t - 1])
@@ -143,15 +160,43 @@ def main():
     events = HipEvents(3 * args.steps)
     ev_floor_us = events.floor_us(torch.cuda.current_stream(dev).cuda_stream)
 
-    def step(i, ev=None):
+    def frame_body(prev_frame, prev_mask, cur_frame):
+        # one frame of the loop; all of the step's work, incl. the final soft-max, is done
+        flow = tfn._forward(cur_frame, prev_frame)
+        logit = net.frame_step(ctx, bank, prev_frame, prev_mask, cur_frame, flow, commit=False)
+        return torch.softmax(logit, dim=1)
+
+    def eager_step(i, ev=None):
         # frames cycle through the clip; the mask fed back is the synthetic blob of frame t-1 (with
         # random-init weights the prediction itself is meaningless and would drive the boxes to
-        # degenerate sizes); all of the step's work, incl. the final soft-max, is still done.
+        # degenerate sizes)
         t = T_MEM + (i % (n_clip - T_MEM))
         net._profile_events = ev
-        flow = tfn._forward(frames[:, t], frames[:, t - 1])
-        logit = net.frame_step(ctx, bank, frames[:, t - 1], masks[:, t - 1], frames[:, t], flow, commit=False)
-        return torch.softmax(logit, dim=1)
+        return frame_body(frames[:, t - 1], masks[:, t - 1], frames[:, t])
+
+    step = eager_step
+    if args.graph:
+        # The frame step has no host synchronisation (boxes, rectangles, split plan all stay on the
+        # device), so it is captured once and replayed; inputs go through static buffers.
+        s_prev, s_mask, s_cur = frames[:, T_MEM - 1].clone(), masks[:, T_MEM - 1].clone(), frames[:, T_MEM].clone()
+        net._profile_events = None
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                frame_body(s_prev, s_mask, s_cur)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            s_out = frame_body(s_prev, s_mask, s_cur)
+
+        def step(i, ev=None):
+            t = T_MEM + (i % (n_clip - T_MEM))
+            s_prev.copy_(frames[:, t - 1])
+            s_mask.copy_(masks[:, t - 1])
+            s_cur.copy_(frames[:, t])
+            graph.replay()
+            return s_out
 
     for i in range(args.warmup):
         step(i)
@@ -166,13 +211,19 @@ def main():
     torch.cuda.synchronize()
     elapsed = rd.max_over_ranks(time.perf_counter() - t0)
     assert bool(torch.isfinite(out).all())
+    if args.graph:
+        # events cannot be read back from inside a replayed graph: time the kernel on the same state
+        # with an eager pass right after the timed region
+        for i in range(args.steps):
+            eager_step(i, tuple(events.ev[3 * i:3 * i + 3]))
+        torch.cuda.synchronize()
     net._profile_events = None
 
     main_ms = [events.elapsed_ms(events.ev[3 * i], events.ev[3 * i + 1]) for i in range(args.steps)]
     comb_ms = [events.elapsed_ms(events.ev[3 * i + 1], events.ev[3 * i + 2]) for i in range(args.steps)]
     main_raw = sum(main_ms) / len(main_ms)
     main_avg = max(main_raw - ev_floor_us * 1e-3, 1e-6)     # kernel time = bracket - empty-bracket floor
-    abytes = algorithmic_bytes(1, T_MEM, ctx.h, ctx.w)
+    abytes = algorithmic_bytes(B * (K_CH - 1), T_MEM, ctx.h, ctx.w)
     achieved = abytes / (main_avg * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'mr_main_hbm_traffic.json')   # from a separate --pmc pass
@@ -182,18 +233,20 @@ def main():
     if rank == 0:
         line = {
             'metric': 'frames/sec at 480p, 1 object, T=5 memory; memory-read HBM GB/s vs peak',
-            'value': round(world * args.steps / elapsed, 3), 'unit': 'frames/s',
+            'value': round(world * B * args.steps / elapsed, 3), 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32 (convs fp32; memory read = split-fp16 MFMA hi*hi+hi*lo+lo*hi with fp32 accumulate, fp32-class accuracy)',
             'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: 480x854 synthetic clip, 1 object (K=2), memory pinned '
-                                   'at T=5, TinyFlowNet + memorize + regional read + decoder per frame',
+            'config': {'workload': 'BASELINE configs[1]: 480x854 synthetic clips, 1 object each (K=2), memory pinned '
+                                   'at T=5, TinyFlowNet + memorize + regional read + decoder per frame; '
+                                   'clips_per_gpu independent clips batched per GPU',
                        'weights': 'procedural random-init (no checkpoint offline)',
                        'prev_mask': 'synthetic blob mask of frame t-1 (object ~18 % of the frame, boxes ~46 % of the cells)',
                        'sharding': 'one clip per rank',
-                       'miopen_find': bool(args.miopen_find)},
+                       'miopen_find': not args.no_miopen_find, 'channels_last': bool(args.channels_last),
+                       'hip_graph': bool(args.graph), 'clips_per_gpu': B},
             'roofline': {'bound': 'hbm', 'kernel': 'bk_main (fused regional memory read, split-fp16 MFMA bank kernel)',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,

@@ -237,6 +237,7 @@ __device__ inline void role_loop(const BArgs& a, const Walk& wk, char* Kl_, char
 #pragma unroll
     for (int it = 0; it < 4; ++it) acc[dt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
   float mref = -INFINITY, lsum = 0.0f;
+  int touch_a = 0, touch_b = 0, sink = 0;
 #if BK_TRACE
   long long* trc = reinterpret_cast<long long*>(a.ws_o + ((size_t)o * a.slots + (a.slots - 1)) * (size_t)kDo * kQT) + (PRODUCER ? 0 : 1024);
   int trn = 0;
@@ -303,7 +304,22 @@ __device__ inline void role_loop(const BArgs& a, const Walk& wk, char* Kl_, char
     // iteration n+1 and is consumed in iteration n+2 -- its latency is never on the critical path.
     const bool has_next2 = it_ + 2 < ntl;
     int t2 = tn, lt2 = ltn;
-    if (has_next2) { advance(t2, lt2, jt0 + it_ + 2); k_load(t2, lt2); }
+    if (has_next2) {
+      advance(t2, lt2, jt0 + it_ + 2);
+      k_load(t2, lt2);
+      if (!PRODUCER) {
+        // L2 warm-up for V of tile n+2: one dword per 128-byte line, 64 lines per wave-instruction,
+        // the four consumer waves cover both 32 KB planes.  The real fragment loads of that tile are
+        // issued a whole tile later (in PV of n+1) and then hit L2 instead of exposing the HBM
+        // latency inside the PV phase.  The touched values are folded into `sink` one tile later
+        // (they are the oldest outstanding loads by then, so the wait is free).
+        const size_t pbase = ((so0 + t2) * tiles_per_slot + lt2) * (size_t)(kDo * kJT * 2) +
+                             (size_t)((wave - 4) * 64 + lane) * 128;
+        sink += touch_a + touch_b;
+        touch_a = *reinterpret_cast<const int*>(b.vh + pbase);
+        touch_b = *reinterpret_cast<const int*>(b.vl + pbase);
+      }
+    }
 
     if (PRODUCER && BK_ABLATE != 3) {
       const int nvalid = tarea[t] - lt * kJT;   // cells of this tile that exist (>= 1)
@@ -437,6 +453,7 @@ __device__ inline void role_loop(const BArgs& a, const Walk& wk, char* Kl_, char
     wm[wave * 16 + l15] = mref;
     wm[kQT + wave * 16 + l15] = lsum;
   }
+  if (!PRODUCER && (sink + touch_a + touch_b) == 0x7fffffff) a.ws_ml[0] = 0.0f;   // keeps the L2 touches alive
 #if BK_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif

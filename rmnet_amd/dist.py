@@ -37,7 +37,7 @@ def init_from_env(backend=None):
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
-        torch.cuda.set_device(local)
+        torch.cuda.set_device(local % torch.cuda.device_count())
     return rank, world, local
 
 
