@@ -54,6 +54,23 @@ __device__ inline void split_f16(float x, _Float16& hi, _Float16& lo) {
   lo = (_Float16)fminf(fmaxf(x - (float)hi, -65504.0f), 65504.0f);
 }
 
+// Reductions over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48) with the gfx950
+// VALU lane swaps (v_permlane16_swap / v_permlane32_swap) instead of ds_bpermute round trips through
+// the LDS: swap(x, x) leaves (even rows, even rows) / (odd rows, odd rows) resp. (low half, low half) /
+// (high half, high half), so one max/add per swap finishes that level in every lane.
+__device__ inline float group4_max(float x) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ inline float group4_sum(float x) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // Position of compact offset j (0..31) inside its 32-cell group of a V row.  The S = K^T Q MFMA
 // leaves lane group g with rows {4g..4g+3} and {16+4g..16+4g+3}; storing V in that order makes
 // those 8 cells one 16-byte chunk (the k index of the O = V P MFMA is then simply 8g + e).
@@ -166,7 +183,7 @@ struct BArgs {
 };
 
 constexpr int kKbuf = kJT * kDe * 2;                       // bytes of one K plane tile (8 KB)
-constexpr int kLdsBytes = 4 * kKbuf                        // K hi/lo x 2 buffers
+constexpr int kLdsBytes = 6 * kKbuf                        // K hi/lo x 3 ring slots
                           + 2 * 4 * 2 * 64 * 16            // P fragments [buf][ntile][hi/lo][lane] x 16 B
                           + 2 * kQT * 4                    // alpha [buf][64]
                           + (kMaxT + 4) * 4                // tile prefix
@@ -181,8 +198,8 @@ constexpr int kRThreads = 512;
 
 // Workgroup = 8 waves (2 per SIMD), 64 compacted queries x one split of the tile list.
 //   waves 0-3 ("producers", static priority 2): S = K^T Q for 16 queries each, online soft-max,
-//              P -> fp16 hi/lo fragments -> LDS; plus a SMALL share of O += V P (32 value channels).
-//   waves 4-7 ("consumers"): O += V P for 96 value channels each.
+//              P -> fp16 hi/lo fragments -> LDS; plus a smaller share of O += V P (48 value channels).
+//   waves 4-7 ("consumers"): O += V P for 80 value channels each.
 //   Wave i and wave i+4 share a SIMD.  Between two barriers the producer runs PV(n) [24 MFMAs],
 //   S(n+1) [24 MFMAs] and the soft-max VALU work of tile n+1, the consumer runs PV(n) [72 MFMAs]:
 //   the matrix pipe sees 120 MFMAs per tile per SIMD and the producer's VALU phase hides under the
@@ -194,19 +211,25 @@ struct Walk {          // per-workgroup constants of the tile walk (all wave-uni
   int t, lt;           // first tile
 };
 
-// One role of the workgroup.  PRODUCER: waves 0-3 (NDT = 2 d-tiles of PV + S + soft-max);
-// consumer: waves 4-7 (NDT = 6 d-tiles of PV).  Separate instantiations keep each role's register
+// One role of the workgroup.  PRODUCER: waves 0-3 (NDT = 3 d-tiles of PV + S + soft-max);
+// consumer: waves 4-7 (NDT = 5 d-tiles of PV).  Separate instantiations keep each role's register
 // set small (a shared body would keep the union of both alive: 268 spills).
 template <bool PRODUCER>
 __device__ inline void role_loop(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
                                  const int* tpre, const int* tarea, int wave, int tid, long long t_entry) {
-  constexpr int NDT = PRODUCER ? 2 : 6;
+  constexpr int NDT = PRODUCER ? 3 : 5;
   const BankView& b = a.b;
   const int o = blockIdx.y;
   const int lane = tid & 63, l15 = lane & 15, g = lane >> 4;
   const int jt0 = wk.jt0, ntl = wk.ntl;
   int t = wk.t, lt = wk.lt;
-  auto advance = [&](int& tt, int& ll, int j) {   // coordinates of global tile j (>= current)
+  // Coordinates of global tile j (>= current), clamped to the split's last tile.  Clamping makes
+  // every prefetch UNCONDITIONAL (a load past the end just re-reads the last tile): with branches
+  // around the loads hipcc cannot count them and falls back to s_waitcnt vmcnt(0), which drains the
+  // loads issued a moment ago and puts their full latency on the critical path of every tile.
+  const int jlast = jt0 + ntl - 1;
+  auto advance = [&](int& tt, int& ll, int j) {
+    j = min(j, jlast);
     while (tpre[tt + 1] <= j) ++tt;                // skips frames with an empty box
     ll = j - tpre[tt];
   };
@@ -214,30 +237,32 @@ __device__ inline void role_loop(const BArgs& a, const Walk& wk, char* Kl_, char
   const size_t tiles_per_slot = (size_t)(b.hwp / kJT);
   // K: a tile is one contiguous 8 KB block per plane; 512 threads x 16 B.  LDS image: row = byte/256,
   // chunk = (byte/16)&15 stored at chunk ^ (row & 15) -> conflict-free ds_read_b128 of the A fragments.
-  half8 kr[2];
-  auto k_load = [&](int tt, int ll) {
+  // Two register sets (A: even iterations, B: odd) so that two K tiles are in flight at any time.
+  half8 krA[2], krB[2];
+  auto k_load = [&](half8 (&kr)[2], int tt, int ll) {
     const size_t off = ((so0 + tt) * b.hwp + (size_t)ll * kJT) * kDe * sizeof(_Float16) + (size_t)tid * 16;
     kr[0] = *reinterpret_cast<const half8*>(b.kh + off);
     kr[1] = *reinterpret_cast<const half8*>(b.kl + off);
   };
   const int krow = tid >> 4;
   const int kdst = krow * 256 + (((tid & 15) ^ (krow & 15)) << 4);
-  auto k_store = [&](int buf) {
+  auto k_store = [&](const half8 (&kr)[2], int buf) {
     *reinterpret_cast<half8*>(Kl_ + buf * 2 * kKbuf + kdst) = kr[0];
     *reinterpret_cast<half8*>(Kl_ + buf * 2 * kKbuf + kKbuf + kdst) = kr[1];
   };
   // V: fragment-ordered planes; this wave's first d-tile and its lane inside a tile's 32 KB plane
-  const int dt0 = PRODUCER ? 2 * wave : 8 + 6 * (wave - 4);
+  const int dt0 = PRODUCER ? 3 * wave : 12 + 5 * (wave - 4);
   const size_t vlane = (size_t)(dt0 * 64 + lane) * 16;
   auto v_tile = [&](int tt, int ll) { return ((so0 + tt) * tiles_per_slot + ll) * (size_t)(kDo * kJT * 2) + vlane; };
-  half8 vh[NDT], vl[NDT];
+  // V fragment registers: set A holds even tiles, set B odd tiles; a set is refilled with tile n+2
+  // right after PV(n) has consumed it, so every V load has two iterations to land.
+  half8 vhA[NDT], vlA[NDT], vhB[NDT], vlB[NDT];
   f32x4 acc[NDT][4];
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
     for (int it = 0; it < 4; ++it) acc[dt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
   float mref = -INFINITY, lsum = 0.0f;
-  int touch_a = 0, touch_b = 0, sink = 0;
 #if BK_TRACE
   long long* trc = reinterpret_cast<long long*>(a.ws_o + ((size_t)o * a.slots + (a.slots - 1)) * (size_t)kDo * kQT) + (PRODUCER ? 0 : 1024);
   int trn = 0;
@@ -252,20 +277,21 @@ __device__ inline void role_loop(const BArgs& a, const Walk& wk, char* Kl_, char
   // ---- prologue: K of the first two tiles and V of the first go out first, the scattered query
   //      loads behind them: all their latencies overlap
   int tn = t, ltn = lt;                            // tile n+1
-  half8 kr2[2] = {kr[0], kr[1]};
-  k_load(t, lt);
-  if (ntl > 1) {
-    advance(tn, ltn, jt0 + 1);
-    const size_t off = ((so0 + tn) * b.hwp + (size_t)ltn * kJT) * kDe * sizeof(_Float16) + (size_t)tid * 16;
-    kr2[0] = *reinterpret_cast<const half8*>(b.kh + off);
-    kr2[1] = *reinterpret_cast<const half8*>(b.kl + off);
-  }
+  k_load(krA, t, lt);
+  advance(tn, ltn, jt0 + 1);
+  k_load(krB, tn, ltn);
   {
     const size_t off = v_tile(t, lt);
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
-      vh[dt] = *reinterpret_cast<const half8*>(b.vh + off + dt * 1024);
-      vl[dt] = *reinterpret_cast<const half8*>(b.vl + off + dt * 1024);
+      vhA[dt] = *reinterpret_cast<const half8*>(b.vh + off + dt * 1024);
+      vlA[dt] = *reinterpret_cast<const half8*>(b.vl + off + dt * 1024);
+    }
+    const size_t off1 = v_tile(tn, ltn);
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      vhB[dt] = *reinterpret_cast<const half8*>(b.vh + off1 + dt * 1024);
+      vlB[dt] = *reinterpret_cast<const half8*>(b.vl + off1 + dt * 1024);
     }
   }
   // query fragments (B operand of S): lane (query l15, group g) holds channels 32ks + 8g + e
@@ -290,110 +316,98 @@ __device__ inline void role_loop(const BArgs& a, const Walk& wk, char* Kl_, char
         qh[PRODUCER ? ks : 0][e] = hi; ql[PRODUCER ? ks : 0][e] = lo;
       }
   }
-  k_store(0);
-  if (ntl > 1) { kr[0] = kr2[0]; kr[1] = kr2[1]; k_store(1); }
-  __syncthreads();
+  // ---- software pipeline (one barrier per tile):
+  //   iteration i :  all waves      PV(i)            reads P[i&1] (published by the barrier of i-1)
+  //                  producers      S(i+1), soft-max writes P[(i+1)&1]  -- one tile AHEAD of the PV
+  //                  all waves      K tile i+2 (registers, requested during i-2) -> LDS ring slot
+  //                                 (i+2)%3, then request K tile i+4 into the same registers
+  //   so the consumers never wait for the producers' soft-max, the producers' VALU phase runs under
+  //   the consumers' MFMAs, and no global-memory latency sits between a barrier and the MFMAs.
+  k_store(krA, 0);
+  k_store(krB, 1);
+  int t2 = tn, lt2 = ltn;                          // tile n+2 (in flight in set A)
+  advance(t2, lt2, jt0 + 2);
+  k_load(krA, t2, lt2);
+  int t3 = t2, lt3 = lt2;                          // tile n+3 (in flight in set B)
+  advance(t3, lt3, jt0 + 3);
+  k_load(krB, t3, lt3);
+
+  // S = K^T Q, online soft-max and P fragments of one tile (producers only)
+  auto s_phase = [&](int tt, int ll, int kslot, int pbuf) {
+    const int nvalid = tarea[tt] - ll * kJT;   // cells of this tile that exist (>= 1)
+    // Four independent accumulator chains: two MFMAs on one accumulator are >= 4 issues apart.
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+    const char* kb = Kl_ + kslot * 2 * kKbuf;
+    {   // all 16 fragment reads in flight, then the 24 MFMAs (producers have the registers for it)
+      half8 a0h[4], a1h[4], a0l[4], a1l[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int sw = ((4 * ks + g) ^ l15) << 4;
+        a0h[ks] = *reinterpret_cast<const half8*>(kb + l15 * 256 + sw);
+        a1h[ks] = *reinterpret_cast<const half8*>(kb + (16 + l15) * 256 + sw);
+        a0l[ks] = *reinterpret_cast<const half8*>(kb + kKbuf + l15 * 256 + sw);
+        a1l[ks] = *reinterpret_cast<const half8*>(kb + kKbuf + (16 + l15) * 256 + sw);
+      }
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const int ks = PRODUCER ? k4 : 0;
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0l[k4], qh[ks], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l[k4], qh[ks], c1, 0, 0, 0);
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h[k4], qh[ks], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h[k4], qh[ks], s1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h[k4], ql[ks], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h[k4], ql[ks], c1, 0, 0, 0);
+      }
+    }
+    s0 += c0;
+    s1 += c1;
+    // lane holds S[cell 4g + r (+16)][query l15]; k index of the P fragment: e = r (+4)
+    float sv[8];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sv[r] = (4 * g + r < nvalid) ? s0[r] * a.inv_sqrt_de : -INFINITY;        // models/rmnet.py:156
+      sv[4 + r] = (16 + 4 * g + r < nvalid) ? s1[r] * a.inv_sqrt_de : -INFINITY;
+      tmax = fmaxf(tmax, fmaxf(sv[r], sv[4 + r]));
+    }
+    tmax = group4_max(tmax);
+    float alpha = 1.0f;
+    if (tmax > mref + kDefer) {        // deferred running reference (first tile: mref = -inf)
+      alpha = __expf(mref - tmax);
+      mref = tmax;
+    }
+    float rs = 0.0f;
+    half8 ph, plo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float pv = __expf(sv[e] - mref);   // in [0, e^8]: no saturation needed for the split
+      rs += pv;
+      const _Float16 hi = (_Float16)pv;
+      ph[e] = hi;
+      plo[e] = (_Float16)(pv - (float)hi);
+    }
+    rs = group4_sum(rs);
+    lsum = lsum * alpha + rs;
+    char* pb = Pl_ + ((pbuf * 4 + wave) * 2) * 1024 + lane * 16;
+    *reinterpret_cast<half8*>(pb) = ph;
+    *reinterpret_cast<half8*>(pb + 1024) = plo;
+    if (g == 0) Al[pbuf * kQT + wave * 16 + l15] = alpha;
+  };
+
+  __syncthreads();                                   // K tiles 0 and 1 visible
+  if (PRODUCER && BK_ABLATE != 3) s_phase(t, lt, 0, 0);
+  __syncthreads();                                   // P(0) visible
   STAMP();
 
-  for (int it_ = 0; it_ < ntl; ++it_) {
+  int ks1 = 1, ks2 = 2;                              // ring slots of tiles n+1 and n+2
+  auto iteration = [&](const int it_, half8 (&kr)[2], half8 (&vh)[NDT], half8 (&vl)[NDT]) {
     const int buf = it_ & 1;
     STAMP();   // loop top
     const bool has_next = it_ + 1 < ntl;
-    // K of tile n+2 is requested now and parked in LDS buffer `buf` at the END of this iteration
-    // (after the barrier nobody reads that buffer any more); it becomes visible with the barrier of
-    // iteration n+1 and is consumed in iteration n+2 -- its latency is never on the critical path.
-    const bool has_next2 = it_ + 2 < ntl;
-    int t2 = tn, lt2 = ltn;
-    if (has_next2) {
-      advance(t2, lt2, jt0 + it_ + 2);
-      k_load(t2, lt2);
-      if (!PRODUCER) {
-        // L2 warm-up for V of tile n+2: one dword per 128-byte line, 64 lines per wave-instruction,
-        // the four consumer waves cover both 32 KB planes.  The real fragment loads of that tile are
-        // issued a whole tile later (in PV of n+1) and then hit L2 instead of exposing the HBM
-        // latency inside the PV phase.  The touched values are folded into `sink` one tile later
-        // (they are the oldest outstanding loads by then, so the wait is free).
-        const size_t pbase = ((so0 + t2) * tiles_per_slot + lt2) * (size_t)(kDo * kJT * 2) +
-                             (size_t)((wave - 4) * 64 + lane) * 128;
-        sink += touch_a + touch_b;
-        touch_a = *reinterpret_cast<const int*>(b.vh + pbase);
-        touch_b = *reinterpret_cast<const int*>(b.vl + pbase);
-      }
-    }
-
-    if (PRODUCER && BK_ABLATE != 3) {
-      const int nvalid = tarea[t] - lt * kJT;   // cells of this tile that exist (>= 1)
-      // ---- S = K^T Q (hi*hi + hi*lo + lo*hi), this wave's 16 queries x 32 cells.  Four independent
-      //      accumulator chains: two MFMAs on one accumulator are always >= 4 issues apart.
-      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-      f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-      const char* kb = Kl_ + buf * 2 * kKbuf;
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {   // 8 fragment reads in flight, then their 12 MFMAs
-        half8 a0h[2], a1h[2], a0l[2], a1l[2];
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-          const int sw = ((4 * (2 * half + k2) + g) ^ l15) << 4;
-          a0h[k2] = *reinterpret_cast<const half8*>(kb + l15 * 256 + sw);
-          a1h[k2] = *reinterpret_cast<const half8*>(kb + (16 + l15) * 256 + sw);
-          a0l[k2] = *reinterpret_cast<const half8*>(kb + kKbuf + l15 * 256 + sw);
-          a1l[k2] = *reinterpret_cast<const half8*>(kb + kKbuf + (16 + l15) * 256 + sw);
-        }
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-          const int ks = PRODUCER ? 2 * half + k2 : 0;
-          c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0l[k2], qh[ks], c0, 0, 0, 0);
-          c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l[k2], qh[ks], c1, 0, 0, 0);
-          s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h[k2], qh[ks], s0, 0, 0, 0);
-          s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h[k2], qh[ks], s1, 0, 0, 0);
-          c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h[k2], ql[ks], c0, 0, 0, 0);
-          c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h[k2], ql[ks], c1, 0, 0, 0);
-        }
-      }
-      s0 += c0;
-      s1 += c1;
-      STAMP();   // S done
-      // lane holds S[cell 4g + r (+16)][query l15]; k index of the P fragment: e = r (+4)
-      float sv[8];
-      float tmax = -INFINITY;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        sv[r] = (4 * g + r < nvalid) ? s0[r] * a.inv_sqrt_de : -INFINITY;        // models/rmnet.py:156
-        sv[4 + r] = (16 + 4 * g + r < nvalid) ? s1[r] * a.inv_sqrt_de : -INFINITY;
-        tmax = fmaxf(tmax, fmaxf(sv[r], sv[4 + r]));
-      }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-      float alpha = 1.0f;
-      if (tmax > mref + kDefer) {        // deferred running reference (first tile: mref = -inf)
-        alpha = __expf(mref - tmax);
-        mref = tmax;
-      }
-      float rs = 0.0f;
-      half8 ph, plo;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float pv = __expf(sv[e] - mref);   // in [0, e^8]: no saturation needed for the split
-        rs += pv;
-        const _Float16 hi = (_Float16)pv;
-        ph[e] = hi;
-        plo[e] = (_Float16)(pv - (float)hi);
-      }
-      rs += __shfl_xor(rs, 16);
-      rs += __shfl_xor(rs, 32);
-      lsum = lsum * alpha + rs;
-      char* pb = Pl_ + ((buf * 4 + wave) * 2) * 1024 + lane * 16;
-      *reinterpret_cast<half8*>(pb) = ph;
-      *reinterpret_cast<half8*>(pb + 1024) = plo;
-      if (g == 0) Al[buf * kQT + wave * 16 + l15] = alpha;
-    }
-    STAMP();   // before barrier
-    __syncthreads();   // the one barrier per tile: P/alpha of this tile (+ K of tile n+1) are visible
-    STAMP();   // after barrier
-
-    // ---- O += V P for this wave's NDT d-tiles x 64 queries
+    // ---- O += V P for this wave's NDT d-tiles x 64 queries (tile n)
     {
-      const size_t noff = has_next ? v_tile(tn, ltn) : 0;
+      const size_t noff = v_tile(t2, lt2);   // refill target: tile n+2 (clamped past the end)
       const char* nvh = b.vh + noff;
       const char* nvl = b.vl + noff;
       const char* pfr = Pl_ + (buf * 4) * 2048;
@@ -428,16 +442,35 @@ __device__ inline void role_loop(const BArgs& a, const Walk& wk, char* Kl_, char
         for (int it = 0; it < 4; ++it)
           acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, bh[it], acc[dt][it], 0, 0, 0);
 #endif
-        if (has_next && BK_ABLATE != 1) {   // refill this fragment for the next tile (a tile ahead)
+        if (BK_ABLATE != 1) {   // refill this fragment with tile n+2 (two tiles ahead), unconditionally
           vh[dt] = *reinterpret_cast<const half8*>(nvh + dt * 1024);
           vl[dt] = *reinterpret_cast<const half8*>(nvl + dt * 1024);
         }
       }
     }
     STAMP();   // PV done
-    if (has_next2) k_store(buf);
+    // ---- producers: S and soft-max of tile n+1 (its K tile became visible with the last barrier)
+    if (PRODUCER && has_next && BK_ABLATE != 3) s_phase(tn, ltn, ks1, buf ^ 1);
+    STAMP();   // S/soft-max done
+    // ---- K ring: tile n+2 (requested two iterations ago) -> slot ks2; request tile n+4 into the
+    //      same registers (the other set holds tile n+3, still in flight)
+    int t4 = t3, lt4 = lt3;
+    k_store(kr, ks2);                                // (a clamped duplicate past the end: harmless)
+    advance(t4, lt4, jt0 + it_ + 4);
+    k_load(kr, t4, lt4);
+    STAMP();   // before barrier
+    __syncthreads();   // the one barrier per tile
+    STAMP();   // after barrier
     t = tn; lt = ltn;
     tn = t2; ltn = lt2;
+    t2 = t3; lt2 = lt3;
+    t3 = t4; lt3 = lt4;
+    ks1 = ks2;
+    ks2 = ks2 == 2 ? 0 : ks2 + 1;
+  };
+  for (int it_ = 0; it_ < ntl; it_ += 2) {
+    iteration(it_, krA, vhA, vlA);
+    if (it_ + 1 < ntl) iteration(it_ + 1, krB, vhB, vlB);
   }
   STAMP();
 
@@ -453,7 +486,6 @@ __device__ inline void role_loop(const BArgs& a, const Walk& wk, char* Kl_, char
     wm[wave * 16 + l15] = mref;
     wm[kQT + wave * 16 + l15] = lsum;
   }
-  if (!PRODUCER && (sink + touch_a + touch_b) == 0x7fffffff) a.ws_ml[0] = 0.0f;   // keeps the L2 touches alive
 #if BK_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -462,8 +494,8 @@ __device__ inline void role_loop(const BArgs& a, const Walk& wk, char* Kl_, char
 
 __global__ __launch_bounds__(kRThreads, 2) void bk_main(const BArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
-  char* Kl_ = lds;                                 // [buf][plane][8 KB]
-  char* Pl_ = lds + 4 * kKbuf;                     // [buf][ntile][plane][lane*16]
+  char* Kl_ = lds;                                 // [ring slot][plane][8 KB]
+  char* Pl_ = lds + 6 * kKbuf;                     // [buf][ntile][plane][lane*16]
   float* Al = reinterpret_cast<float*>(Pl_ + 2 * 4 * 2 * 64 * 16);
   int* tpre = reinterpret_cast<int*>(Al + 2 * kQT);
   int* tarea = tpre + kMaxT + 4;
@@ -473,7 +505,10 @@ __global__ __launch_bounds__(kRThreads, 2) void bk_main(const BArgs a) {
   const int tid = threadIdx.x, o = blockIdx.y;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool producer = wave < 4;
-  if (producer) __builtin_amdgcn_s_setprio(2);
+#ifndef BK_PRIO
+#define BK_PRIO 2
+#endif
+  if (producer && BK_PRIO > 0) __builtin_amdgcn_s_setprio(BK_PRIO);
 
   // ---- plan: tile prefix over the T memorised frames, query rectangle, split decode.  The query
   //      rectangle load is issued first so that its latency overlaps the area loads.

@@ -93,7 +93,10 @@ BankView bank_view(void* base, int no, int Tcap, int h, int w);
 size_t bank_bytes(int no, int Tcap, int h, int w);
 
 // Split heuristic shared by the read kernels and the combine kernel (must agree exactly).
-constexpr int kSplitTargetSlots = 256;   // workgroups per launch to aim for (one per CU)
+#ifndef RMNET_SPLIT_TARGET
+#define RMNET_SPLIT_TARGET 256
+#endif
+constexpr int kSplitTargetSlots = RMNET_SPLIT_TARGET;   // workgroups per launch to aim for (one per CU)
 constexpr int kSplitMinTiles = 2;        // a split must amortise its prologue + 128 KB partial
 constexpr int kSplitMax = 64;
 struct BankPlan { int nqt, nsplit; };

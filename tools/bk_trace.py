@@ -32,10 +32,10 @@ for name, a in (('producer wave0', tr[:1024]), ('consumer wave4', tr[1024:2048])
     d = np.diff(a)
     print(name, 'n stamps', len(a), 'total', a[-1] - a[0])
     print('  all deltas' if len(d) < 40 else '  first 12 deltas', d[:40] if len(d) < 40 else d[:12])
-    per = 5 if 'producer' in name else 4
+    per = 5
     nfull = min(20, (len(d) - 4) // per)
     if nfull < 1:
         continue
     body = d[3:3 + per * nfull].reshape(-1, per)
-    print('  labels:', ['top->S done', 'softmax->pre-barrier', 'barrier', 'PV', '->next top'] if per == 5 else ['top->pre-barrier', 'barrier', 'PV', '->next top'])
+    print('  labels:', ['top->PV done', 'S+softmax', 'K ring', 'barrier', '->next top'])
     print('  per-iteration deltas (mean over its):', body.mean(0).round(0), 'sum', body.mean(0).sum())

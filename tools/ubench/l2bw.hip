@@ -41,9 +41,10 @@ __global__ __launch_bounds__(512) void dma(const f4* __restrict__ src, size_t n_
   if (s == 12345.f) sink[0] = s;
 }
 
-int main() {
-  const size_t bytes = 2u << 20;  // 2 MB region: L2 resident per XCD
+int run_size(size_t mb) {
+  const size_t bytes = mb << 20;
   const size_t n_f4 = bytes / 16;
+  printf("---- footprint %zu MB (every WG streams the same region from a different offset)\n", mb);
   f4* src; float* sink;
   hipMalloc(&src, bytes); hipMalloc(&sink, 64); hipMemset(src, 0, bytes);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -56,12 +57,15 @@ int main() {
     printf("%-10s D=%2d grid=%3d : %8.1f GB/s total, %6.1f GB/s per WG (%.1f B/clk at 2.1 GHz)\n", name, D, grid,
            total / ms / 1e6, total / ms / 1e6 / grid, total / ms / 1e6 / grid / 2.1);
   };
-  for (int grid : {1, 32, 256}) {
-    run("plain", [&](int g, int it) { hipLaunchKernelGGL(plain<1>, dim3(g), dim3(512), 0, 0, src, n_f4, it, sink); }, 1, grid);
-    run("plain", [&](int g, int it) { hipLaunchKernelGGL(plain<4>, dim3(g), dim3(512), 0, 0, src, n_f4, it, sink); }, 4, grid);
+  for (int grid : {256}) {
     run("plain", [&](int g, int it) { hipLaunchKernelGGL(plain<8>, dim3(g), dim3(512), 0, 0, src, n_f4, it, sink); }, 8, grid);
     run("plain", [&](int g, int it) { hipLaunchKernelGGL(plain<16>, dim3(g), dim3(512), 0, 0, src, n_f4, it, sink); }, 16, grid);
-    run("dma", [&](int g, int it) { hipLaunchKernelGGL(dma, dim3(g), dim3(512), 0, 0, src, n_f4, it, sink, 8); }, 8, grid);
   }
+  hipFree(src); hipFree(sink);
+  return 0;
+}
+
+int main() {
+  for (size_t mb : {2, 4, 8, 16, 32, 128, 512}) run_size(mb);
   return 0;
 }
