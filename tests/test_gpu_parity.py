@@ -442,3 +442,76 @@ def test_tiny_flownet_on_gpu(golden_dir):
     with torch.no_grad():
         fl = net(cu(g['frames']))
     np.testing.assert_allclose(fl.cpu().numpy(), g['flows'], atol=2e-3, rtol=1e-3)
+
+
+# ----------------------------------------------------------------------------- wider loop coverage
+def _clip_with_late_object(N, H, W, seed):
+    """K = 3 clip in which object 2 only appears at frame 2 (n_objects changes mid-clip): exercises
+    the new-object injection and the 'non-existing object' logits of models/rmnet.py:436-448."""
+    from rmnet_amd.synthetic import synthetic_clip
+    frames, masks, flows, _ = synthetic_clip(N, 3, H, W, seed=seed, size=1.3)
+    masks = masks.clone()
+    for t in range(2):                       # object 2 is background in frames 0 and 1
+        masks[0, t, 0] = masks[0, t, 0] | masks[0, t, 2]
+        masks[0, t, 2] = 0
+    n_objects = torch.tensor([[1, 1] + [2] * (N - 2)], dtype=torch.long)
+    return frames, masks, flows, n_objects
+
+
+def test_rmnet_new_object_and_batch_of_clips(oracle_mod):
+    prod, ref = _nets(oracle_mod)
+    f1, m1, fl1, n1 = _clip_with_late_object(5, 96, 160, seed=11)
+    f2, m2, fl2, n2 = _clip_with_late_object(5, 96, 160, seed=12)
+    n2 = torch.full_like(n2, 2)
+    from rmnet_amd.synthetic import synthetic_clip
+    f2, m2, fl2, _ = synthetic_clip(5, 3, 96, 160, seed=12, size=1.3)
+    frames, masks = torch.cat([f1, f2]), torch.cat([m1, m2])
+    flows, n_objects = torch.cat([fl1, fl2]), torch.cat([n1, n2])
+    with torch.no_grad():
+        est = prod(frames, masks, flows, n_objects, 2).cpu()
+        est_cpu = ref(frames, masks, flows, n_objects, 2)
+    assert float((est - est_cpu).abs().max()) < 1e-3
+    lab, lab_cpu = est.argmax(2).numpy(), est_cpu.argmax(2).numpy()
+    assert (lab == lab_cpu).mean() > 0.999
+    # before it appears, object 2 of clip 0 has (numerically) zero probability
+    assert float(est[0, 1, 2].max()) < 1e-6
+
+
+def test_frame_step_is_graph_capturable(oracle_mod):
+    """No host synchronisation inside a frame step: it can be captured into a HIP graph and replayed
+    (boxes, rectangles and the split plan all stay on the device)."""
+    from rmnet_amd.synthetic import synthetic_clip
+    prod, _ = _nets(oracle_mod)
+    d = dev()
+    frames, masks, flows, _ = synthetic_clip(4, 2, 96, 160, seed=5, size=1.5)
+    frames, masks, flows = frames.to(d), masks.to(d).float(), flows.to(d)
+    ctx = prod._ClipContext(prod, 1, 2, 96, 160, [1], d)
+    bank = prod.new_bank(ctx, 3)
+    with torch.no_grad():
+        prod.frame_step(ctx, bank, frames[:, 0], masks[:, 0], frames[:, 1], flows[:, 1], commit=True)
+        eager = prod.frame_step(ctx, bank, frames[:, 1], masks[:, 1], frames[:, 2], flows[:, 2], commit=False).clone()
+        side = torch.cuda.Stream(d)
+        side.wait_stream(torch.cuda.current_stream(d))
+        with torch.cuda.stream(side):
+            prod.frame_step(ctx, bank, frames[:, 1], masks[:, 1], frames[:, 2], flows[:, 2], commit=False)
+        torch.cuda.current_stream(d).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = prod.frame_step(ctx, bank, frames[:, 1], masks[:, 1], frames[:, 2], flows[:, 2], commit=False)
+        g.replay()
+        torch.cuda.synchronize()
+    diff = float((out - eager).abs().max())
+    assert diff < 1e-3, diff     # same kernels; MIOpen may pick another algorithm under capture
+
+
+def test_long_memory_bank_and_fp32_kernel(oracle_mod):
+    """T = 70 memorised frames (> one wave of the prefix scans), many empty boxes."""
+    from rmnet_amd import ops
+    rng = np.random.RandomState(70)
+    no, T, h, w = 1, 70, 5, 6
+    mk, mv, qk, qv, mr, qr = _random_case(rng, no, T, h, w, regional=True)
+    want, _ = oracle_mod.regional_memory_read(mk, mv, qk, qv, mr, qr)
+    got, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), cu(mr), cu(qr))
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL)
+    bank = _fill_bank(ops, mk, mv, mr)
+    np.testing.assert_allclose(bank.read(T, cu(qk), cu(qv), cu(qr)).cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL)
