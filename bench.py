@@ -225,6 +225,19 @@ def main():
     main_avg = max(main_raw - ev_floor_us * 1e-3, 1e-6)     # kernel time = bracket - empty-bracket floor
     abytes = algorithmic_bytes(B * (K_CH - 1), T_MEM, ctx.h, ctx.w)
     achieved = abytes / (main_avg * 1e-3) / 1e9
+    # executed MFMA work of the same launches: 3 split-fp16 terms over the COMPACTED tiles
+    areas = bank.areas()[:, :T_MEM].cpu()
+    njt = ((areas + 31) // 32).sum(dim=1)                              # 32-cell tiles per object
+    lw_, _, lh_, _ = __import__('rmnet_amd.helpers', fromlist=['pad_amounts']).pad_amounts(H, W, 16)
+    t_last = T_MEM + ((args.steps - 1) % (n_clip - T_MEM))
+    from rmnet_amd import ops as _ops
+    _, _, qr = _ops.region_map(net.warp(masks[:, t_last - 1], tfn._forward(frames[:, t_last], frames[:, t_last - 1]))[0].contiguous(),
+                               want_map=False, cell_grid=(lw_, lh_, 16, ctx.h, ctx.w))
+    qr = qr[:, 1].cpu()
+    mq = (qr[:, 1] - qr[:, 0] + 1).clamp(min=0) * (qr[:, 3] - qr[:, 2] + 1).clamp(min=0)
+    nqt = (mq + 1 + 63) // 64
+    mfma_flops = float((nqt * 64 * njt * 32).sum()) * (DE + DO) * 2 * 3
+    mfma_tflops = mfma_flops / (main_avg * 1e-3) / 1e12
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'mr_main_hbm_traffic.json')   # from a separate --pmc pass
     if os.path.exists(tpath):
@@ -254,6 +267,10 @@ def main():
                          'avg_us': round(main_avg * 1e3, 2), 'avg_us_event_bracket': round(main_raw * 1e3, 2),
                          'event_floor_us': round(ev_floor_us, 2), 'min_us_event_bracket': round(min(main_ms) * 1e3, 2),
                          'combine_avg_us_event_bracket': round(sum(comb_ms) / len(comb_ms) * 1e3, 2),
+                         'mfma': {'executed_tflops': round(mfma_tflops, 1), 'peak_f16_dense_tflops': 2500.0,
+                                  'frac': round(mfma_tflops / 2500.0, 4),
+                                  'note': 'v_mfma_f32_16x16x32_f16, three split-fp16 terms (hi*hi+hi*lo+lo*hi) over the '
+                                          'compacted 64-query x 32-cell tiles actually executed'},
                          'timing': 'hipEventRecord on the launch stream around every bk_main of the timed region; '
                                    'avg_us = bracket mean minus the empty-bracket floor measured the same way'},
         }

@@ -192,6 +192,9 @@ constexpr int kRThreads = 512;
 #ifndef BK_TRACE
 #define BK_TRACE 0     // experiments only: per-phase s_memtime stamps of block 0, waves 0 and 4
 #endif
+#ifndef BK_PDT
+#define BK_PDT 3     // d-tiles of PV per producer wave (consumers take 8 - BK_PDT)
+#endif
 #ifndef BK_ABLATE
 #define BK_ABLATE 0   // experiments only: 1 = no V reloads, 2 = no PV MFMAs, 3 = no S/soft-max
 #endif                             // 8 waves = 2 per SIMD
@@ -217,7 +220,7 @@ struct Walk {          // per-workgroup constants of the tile walk (all wave-uni
 template <bool PRODUCER>
 __device__ inline void role_loop(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
                                  const int* tpre, const int* tarea, int wave, int tid, long long t_entry) {
-  constexpr int NDT = PRODUCER ? 3 : 5;
+  constexpr int NDT = PRODUCER ? BK_PDT : (8 - BK_PDT);
   const BankView& b = a.b;
   const int o = blockIdx.y;
   const int lane = tid & 63, l15 = lane & 15, g = lane >> 4;
@@ -251,7 +254,7 @@ __device__ inline void role_loop(const BArgs& a, const Walk& wk, char* Kl_, char
     *reinterpret_cast<half8*>(Kl_ + buf * 2 * kKbuf + kKbuf + kdst) = kr[1];
   };
   // V: fragment-ordered planes; this wave's first d-tile and its lane inside a tile's 32 KB plane
-  const int dt0 = PRODUCER ? 3 * wave : 12 + 5 * (wave - 4);
+  const int dt0 = PRODUCER ? BK_PDT * wave : 4 * BK_PDT + (8 - BK_PDT) * (wave - 4);
   const size_t vlane = (size_t)(dt0 * 64 + lane) * 16;
   auto v_tile = [&](int tt, int ll) { return ((so0 + tt) * tiles_per_slot + ll) * (size_t)(kDo * kJT * 2) + vlane; };
   // V fragment registers: set A holds even tiles, set B odd tiles; a set is refilled with tile n+2
@@ -411,14 +414,13 @@ __device__ inline void role_loop(const BArgs& a, const Walk& wk, char* Kl_, char
       const char* nvh = b.vh + noff;
       const char* nvl = b.vl + noff;
       const char* pfr = Pl_ + (buf * 4) * 2048;
-      half8 bh[4], bl[4];
       float al[4];
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        bh[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + lane * 16);
-        bl[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + 1024 + lane * 16);
-        al[it] = Al[buf * kQT + it * 16 + l15];
-      }
+      for (int it = 0; it < 4; ++it) al[it] = Al[buf * kQT + it * 16 + l15];
+      // P fragments are consumed one query tile at a time (16 registers live instead of 32); the
+      // NDT accumulators touched between two uses of the same accumulator keep the MFMAs independent.
+      half8 bh = *reinterpret_cast<const half8*>(pfr + lane * 16);
+      half8 bl = *reinterpret_cast<const half8*>(pfr + 1024 + lane * 16);
       if (__any(al[0] != 1.0f || al[1] != 1.0f || al[2] != 1.0f || al[3] != 1.0f)) {
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
@@ -426,30 +428,35 @@ __device__ inline void role_loop(const BArgs& a, const Walk& wk, char* Kl_, char
           for (int it = 0; it < 4; ++it) acc[dt][it] *= al[it];
       }
 #pragma unroll
-      for (int dt = 0; dt < NDT; ++dt) {
-        const half8 xh = vh[dt], xl = vl[dt];
-#if BK_ABLATE == 2
-        asm volatile("" ::"v"(xh), "v"(xl));
-#else
-        // term-major order: the three MFMAs of one accumulator are 4 issues apart
+      for (int it = 0; it < 4; ++it) {
+        const half8 ch = bh, cl = bl;
+        if (it < 3) {   // next query tile's fragments: their LDS latency hides under this tile's MFMAs
+          bh = *reinterpret_cast<const half8*>(pfr + (it + 1) * 2048 + lane * 16);
+          bl = *reinterpret_cast<const half8*>(pfr + (it + 1) * 2048 + 1024 + lane * 16);
+        }
+#if BK_ABLATE != 2
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
-          acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, bh[it], acc[dt][it], 0, 0, 0);
+        for (int dt = 0; dt < NDT; ++dt)
+          acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[dt], ch, acc[dt][it], 0, 0, 0);
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
-          acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, bl[it], acc[dt][it], 0, 0, 0);
+        for (int dt = 0; dt < NDT; ++dt)
+          acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[dt], cl, acc[dt][it], 0, 0, 0);
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
-          acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, bh[it], acc[dt][it], 0, 0, 0);
+        for (int dt = 0; dt < NDT; ++dt)
+          acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[dt], ch, acc[dt][it], 0, 0, 0);
 #endif
-        if (BK_ABLATE != 1) {   // refill this fragment with tile n+2 (two tiles ahead), unconditionally
+      }
+      if (BK_ABLATE != 1) {   // refill this set with tile n+2 (two tiles ahead), unconditionally
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
           vh[dt] = *reinterpret_cast<const half8*>(nvh + dt * 1024);
           vl[dt] = *reinterpret_cast<const half8*>(nvl + dt * 1024);
         }
       }
     }
     STAMP();   // PV done
-    // ---- producers: S and soft-max of tile n+1 (its K tile became visible with the last barrier)
+    // ---- producers: S and soft-max of tile n+1 (its K tile became visible with the last barrier).
+    //      (Doing this BEFORE the producers' own PV share was measured 4 % slower.)
     if (PRODUCER && has_next && BK_ABLATE != 3) s_phase(tn, ltn, ks1, buf ^ 1);
     STAMP();   // S/soft-max done
     // ---- K ring: tile n+2 (requested two iterations ago) -> slot ks2; request tile n+4 into the

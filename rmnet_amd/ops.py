@@ -160,6 +160,13 @@ class MemoryBank:
                                            _ptr(k4), _ptr(v4), _ptr(rects), _stream(self.device))
         _lib.check(rc, 'rmnet_bank_append_f32')
 
+    def areas(self):
+        """[no, capacity] int32 view of the per-slot cell counts kept at the tail of the blob (debug /
+        accounting only; mirrors bank_view() in csrc/bank.hip)."""
+        hwp = (self.h * self.w + 31) // 32 * 32
+        off = 2 * self.no * self.capacity * hwp * 128 * 2 + 2 * self.no * self.capacity * 512 * hwp * 2
+        return self.blob[off:off + self.no * self.capacity * 4].view(torch.int32).view(self.no, self.capacity)
+
     def stage(self, k4, v4, rects):
         """Write one frame into the first free slot without committing it (the tentative previous
         frame of models/rmnet.py:416-426).  Returns the number of frames visible to ``read``."""
