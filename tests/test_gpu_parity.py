@@ -515,3 +515,22 @@ def test_long_memory_bank_and_fp32_kernel(oracle_mod):
     np.testing.assert_allclose(got.cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL)
     bank = _fill_bank(ops, mk, mv, mr)
     np.testing.assert_allclose(bank.read(T, cu(qk), cu(qv), cu(qr)).cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL)
+
+
+def test_batchnorm_folding_keeps_the_masks(golden_dir, oracle_mod):
+    """fuse_for_inference() (BN folded into the trunk convolutions) == the un-folded network."""
+    import copy
+    from rmnet_amd.synthetic import synthetic_clip
+    prod, _ = _nets(oracle_mod)
+    for m in prod.modules():                      # non-trivial statistics, otherwise folding is a no-op
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.uniform_(-0.1, 0.1)
+            m.running_var.uniform_(0.8, 1.25)
+    fused = copy.deepcopy(prod).fuse_for_inference()
+    assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in fused.modules())
+    frames, masks, flows, n_objects = synthetic_clip(3, 3, 96, 160, seed=9, size=1.3)
+    with torch.no_grad():
+        a = prod(frames, masks, flows, n_objects, 1)
+        b = fused(frames, masks, flows, n_objects, 1)
+    assert float((a - b).abs().max()) < 1e-3
+    assert (a.argmax(2) == b.argmax(2)).float().mean() > 0.999

@@ -8,7 +8,7 @@ from rmnet_amd import ops
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import HipEvents, algorithmic_bytes
 
-CFG = {1: (1, 3, 30, 54), 2: (1, 5, 30, 54), 3: (5, 5, 30, 54), 5: (3, 20, 45, 80)}
+CFG = {1: (1, 3, 30, 54), 2: (1, 5, 30, 54), 3: (5, 5, 30, 54), 4: (4, 5, 30, 54), 5: (3, 20, 45, 80)}
 
 def rect_of(frac, h, w):
     rh, rw = max(1, int(round(h * frac ** 0.5))), max(1, int(round(w * frac ** 0.5)))
