@@ -152,21 +152,43 @@ __global__ __launch_bounds__(kThreads) void bk_append(BankView b, int slot,
     *reinterpret_cast<half8*>(b.kl + off) = l0;
     *reinterpret_cast<half8*>(b.kl + off + 16) = l1;
   }
-  // values: gather [d][cell] -> split -> fragment order [tile u][d/16][lane][e]
-  const float* vb = v4 + (size_t)o * kDo * b.hw + cell;
-  const int pp = kperm(p);
-  const size_t vbase = (so * (b.hwp / kJT) + u) * (size_t)(kDo * kJT);   // halfs
-  _Float16* vh = reinterpret_cast<_Float16*>(b.vh) + vbase;
-  _Float16* vl = reinterpret_cast<_Float16*>(b.vl) + vbase;
-#pragma unroll 8
-  for (int i = 0; i < kDo / 8; ++i) {
-    const int d = rg + 8 * i;
-    const float x = valid ? vb[(size_t)d * b.hw] : 0.0f;
-    _Float16 hi, lo;
-    split_f16(x, hi, lo);
-    const int idx = (((d >> 4) * 64) + (d & 15) + 16 * (pp >> 3)) * 8 + (pp & 7);
-    vh[idx] = hi;
-    vl[idx] = lo;
+  // values: gather [d][cell] -> split -> fragment order [tile u][d/16][lane = d%16 + 16 g][8 cells].
+  // One thread builds one whole 16-byte fragment row (channel d, lane group gg): its 8 cells are the
+  // compact offsets {4gg..4gg+3, 16+4gg..16+4gg+3} (kperm), fetched with 8 scalar gathers, split, and
+  // written with ONE 16-byte store per plane; a wave covers 16 channels x 4 groups = 4 x 256 B runs.
+  {
+    const int gg = tid & 3;
+    int cells[8];
+    bool ok[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int j = 4 * gg + (e & 3) + 16 * (e >> 2);
+      const int nn = u * kJT + j;
+      ok[e] = nn < area;
+      int cc = 0;
+      if (ok[e]) {
+        const int rw = rc.width(), ry = nn / rw;
+        cc = (rc.cy0 + ry) * b.w + rc.cx0 + (nn - ry * rw);
+      }
+      cells[e] = cc;
+    }
+    const float* vb = v4 + (size_t)o * kDo * b.hw;
+    const size_t vbase = (so * (b.hwp / kJT) + u) * (size_t)(kDo * kJT) * sizeof(_Float16);
+#pragma unroll 2
+    for (int i = 0; i < kDo / 64; ++i) {
+      const int d = (tid >> 2) + 64 * i;
+      half8 hi8, lo8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = ok[e] ? vb[(size_t)d * b.hw + cells[e]] : 0.0f;
+        _Float16 hi, lo;
+        split_f16(x, hi, lo);
+        hi8[e] = hi; lo8[e] = lo;
+      }
+      const size_t off = vbase + (size_t)(((d >> 4) * 64) + (d & 15) + 16 * gg) * 16;
+      *reinterpret_cast<half8*>(b.vh + off) = hi8;
+      *reinterpret_cast<half8*>(b.vl + off) = lo8;
+    }
   }
 }
 
