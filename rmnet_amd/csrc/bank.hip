@@ -23,14 +23,14 @@
 //
 // bk_append : one launch per memorised frame.  Reads k4/v4 (fp32, the reference's NCHW layout) once,
 //             compacts to the box, splits, transposes K through LDS, permutes V, writes the slot.
-// bk_main   : the read.  Workgroup = 4 waves = 64 compacted queries x one split of the tile list.
-//             wave w computes S for its own 16 queries (v_mfma_f32_16x16x32_f16, K tile shared
-//             through swizzled LDS, double-buffered, filled with 16-byte coalesced loads), does the
-//             online soft-max in registers (a query's row lives in 4 lanes x 8 registers), splits P
-//             to fp16 hi/lo in the MFMA B-fragment layout and publishes the fragments in LDS;
-//             then accumulates O += V P for ITS 128 value channels x all 64 queries, with the V
-//             A-fragments loaded straight from the bank into registers (16 B / lane, no LDS, no
-//             transpose) one tile ahead.  ONE barrier per 32-cell tile.
+// bk_main   : the read.  Workgroup = 12 waves = 64 compacted queries x one split of the tile list.
+//             4 producer waves compute S for 16 queries each (v_mfma_f32_16x16x32_f16, K tile shared
+//             through swizzled LDS, filled by LDS-DMA), do the online soft-max in registers (a
+//             query's row lives in 4 lanes x 8 registers), split P to fp16 hi/lo in the MFMA
+//             B-fragment layout and publish the fragments in LDS; 8 consumer waves accumulate
+//             O += V P for 64 value channels x all 64 queries each, with the V A-fragments loaded
+//             straight from the bank into registers (16 B / lane, no LDS, no transpose) two tiles
+//             ahead.  ONE barrier per 32-cell tile.
 // bk_combine: (memory_read.hip's mr_combine, shared) merges the splits, adds the closed-form term
 //             for the masked memory cells, scatters to query cells, appends q_val * box.
 #include "common.h"
@@ -42,11 +42,13 @@ constexpr int kDe = 128, kDo = 512;
 constexpr int kQT = 64, kJT = 32;
 constexpr int kThreads = 256;
 constexpr int kMaxT = 512;
-constexpr float kDefer = 8.0f;   // P <= e^8 stays far inside fp16 range (65504)
+constexpr float kDeferLog2 = 11.5415603f;   // 8 * log2(e): P <= e^8 stays far inside fp16 range (65504)
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2 __attribute__((ext_vector_type(2)));
 
 __device__ inline void split_f16(float x, _Float16& hi, _Float16& lo) {
   const float c = fminf(fmaxf(x, -65504.0f), 65504.0f);   // saturate instead of inf/NaN
@@ -197,131 +199,111 @@ struct BArgs {
   BankView b;
   const float *qk, *qv;
   const int32_t* qry_rects;  // [no][4] or null
-  float* ws_o;               // [no][slots][kDo][kQT]
-  float* ws_ml;              // [no][slots][2][kQT]
+  float* ws_o;               // [no][slots] partial blocks in fragment order (common.h)
+  float* ws_ml;              // [no][slots][2][kQT]: running reference (log2 domain) and sum
   int32_t* ws_plan;          // [no][kPlanInts]
   int T, slots;
-  float inv_sqrt_de;
+  float qscale;              // log2(e) / sqrt(De), folded into the query fragments
 };
 
 constexpr int kKbuf = kJT * kDe * 2;                       // bytes of one K plane tile (8 KB)
-constexpr int kLdsBytes = 6 * kKbuf                        // K hi/lo x 3 ring slots
-                          + 2 * 4 * 2 * 64 * 16            // P fragments [buf][ntile][hi/lo][lane] x 16 B
-                          + 2 * kQT * 4                    // alpha [buf][64]
+constexpr int kPbuf = 4 * 2 * 64 * 16;                     // P fragments of one tile [ntile][hi/lo][lane] x 16 B
+constexpr int kLdsBytes = 8 * kKbuf                        // K hi/lo x 4 ring slots
+                          + 2 * kPbuf                      // P double buffer
+                          + 2 * kQT * 4                    // alpha [buf][16 queries][4 query tiles]
                           + (kMaxT + 4) * 4                // tile prefix
                           + kMaxT * 4;                     // cells per frame
-constexpr int kRThreads = 512;
+constexpr int kProducers = 4;                              // waves 0-3
+constexpr int kConsumers = 8;                              // waves 4-11
+constexpr int kCDT = kDo / 16 / kConsumers;                // d-tiles (16 value channels) per consumer: 4
+constexpr int kRThreads = 64 * (kProducers + kConsumers);  // 768 = 12 waves = 3 per SIMD
 #ifndef BK_TRACE
-#define BK_TRACE 0     // experiments only: per-phase s_memtime stamps of block 0, waves 0 and 4
-#endif
-#ifndef BK_PDT
-#define BK_PDT 3     // d-tiles of PV per producer wave (consumers take 8 - BK_PDT)
+#define BK_TRACE 0     // experiments only: per-phase cycle stamps of block 0, waves 0 and 4
 #endif
 #ifndef BK_ABLATE
-#define BK_ABLATE 0   // experiments only: 1 = no V reloads, 2 = no PV MFMAs, 3 = no S/soft-max
-#endif                             // 8 waves = 2 per SIMD
+#define BK_ABLATE 0    // experiments only, bit mask: 1 no V reloads, 2 no PV MFMAs, 4 no S/soft-max,
+#endif                 //                             8 no partial stores, 16 no K tile loads
+#ifndef BK_PRIO
+#define BK_PRIO 2
+#endif
+#ifndef BK_SCHED
+#define BK_SCHED 1
+#endif
 
-// Workgroup = 8 waves (2 per SIMD), 64 compacted queries x one split of the tile list.
-//   waves 0-3 ("producers", static priority 2): S = K^T Q for 16 queries each, online soft-max,
-//              P -> fp16 hi/lo fragments -> LDS; plus a smaller share of O += V P (48 value channels).
-//   waves 4-7 ("consumers"): O += V P for 80 value channels each.
-//   Wave i and wave i+4 share a SIMD.  Between two barriers the producer runs PV(n) [24 MFMAs],
-//   S(n+1) [24 MFMAs] and the soft-max VALU work of tile n+1, the consumer runs PV(n) [72 MFMAs]:
-//   the matrix pipe sees 120 MFMAs per tile per SIMD and the producer's VALU phase hides under the
-//   consumer's MFMAs.  V A-fragments stream from the bank one tile ahead (1 KB contiguous per wave
-//   load); K tiles run two tiles ahead through registers into a double-buffered swizzled LDS tile.
+// Workgroup = 12 waves (3 per SIMD), 64 compacted queries x one split of the tile list.
+//   waves 0-3  ("producers", static priority): S = K^T Q for 16 queries each (24 MFMAs per 32-cell
+//               tile), online soft-max in registers, P -> fp16 hi/lo B-fragments -> LDS; the MFMAs
+//               of tile n+2 are interleaved with the soft-max VALU chain of tile n+1.
+//   waves 4-11 ("consumers"): O += V P for 64 value channels x 64 queries each (48 MFMAs per tile),
+//               V A-fragments straight from the bank into registers two tiles ahead; they also
+//               move the K tiles bank -> registers -> swizzled LDS ring (they have the slack).
+//   Wave i, i+4 and i+8 share a SIMD: the matrix pipe of every SIMD sees 24 + 2 x 48 = 120 MFMAs per
+//   tile.  The producer's serial chain (LDS fragment reads -> MFMAs -> soft-max VALU -> LDS publish)
+//   is shorter than that and runs one tile AHEAD of the PV, so the consumers never wait for it.
+//   (The previous 8-wave version gave the producers a PV share as well; its trace showed the
+//   producer chain = PV share + S + soft-max as the critical path of every tile, 2x the MFMA time.)
+//   ONE barrier per tile.
 struct Walk {          // per-workgroup constants of the tile walk (all wave-uniform)
   int jt0, ntl, qt, L, Mq;
   Rect qr;
-  int t, lt;           // first tile
+  int t;               // frame of the first tile
 };
 
-// One role of the workgroup.  PRODUCER: waves 0-3 (NDT = 3 d-tiles of PV + S + soft-max);
-// consumer: waves 4-7 (NDT = 5 d-tiles of PV).  Separate instantiations keep each role's register
-// set small (a shared body would keep the union of both alive: 268 spills).
-template <bool PRODUCER>
-__device__ inline void role_loop(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
-                                 const int* tpre, const int* tarea, int wave, int tid, long long t_entry) {
-  constexpr int NDT = PRODUCER ? BK_PDT : (8 - BK_PDT);
+// Wave-uniform cursor over the split's tile list.  seek(j) clamps j to the split's last tile, which
+// makes every prefetch UNCONDITIONAL (a load past the end re-reads the last tile): with branches
+// around the loads hipcc cannot count them and falls back to s_waitcnt vmcnt(0), which drains the
+// loads issued a moment ago.  The frame boundary lives in registers; the LDS prefix is only read
+// when a frame ends.
+struct Cursor {
+  int tt, base, nextb, jlast;
+  const int* tpre;
+  __device__ inline void init(const int* tp, int frame, int jl) {
+    tpre = tp; tt = frame; jlast = jl;
+    base = __builtin_amdgcn_readfirstlane(tp[frame]);
+    nextb = __builtin_amdgcn_readfirstlane(tp[frame + 1]);
+  }
+  __device__ inline int seek(int j) {   // returns the tile's index inside its frame
+    j = min(j, jlast);
+    while (j >= nextb) {                // (also skips frames with an empty box)
+      ++tt;
+      base = nextb;
+      nextb = __builtin_amdgcn_readfirstlane(tpre[tt + 1]);
+    }
+    return j - base;
+  }
+};
+
+#if BK_TRACE
+#define BK_STAMP() do { if (trace_on && trn < 1000) trc[trn++] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define BK_STAMP() do {} while (0)
+#endif
+
+// ---------------------------------------------------------------- producers: S and soft-max
+// Barrier protocol (identical count in consumer_loop): A, B, then one per tile.
+//   pre A        consumers: K(0..3) -> ring slots 0..3
+//   between A, B producers: S(0), S(1), soft-max(0) -> P[0], fragments of K(2); consumers: request K(4)
+//   iteration n  producers: S(n+2) INTERLEAVED with soft-max(n+1) -> P[(n+1)&1]; then the fragments
+//                           of K(n+3) from slot (n+3)%4, so the next iteration starts with MFMAs
+//                consumers: PV(n) from P[n&1]; K(n+4) -> slot n%4 (last read in iteration n-3)
+// The S MFMAs of tile n+2 and the soft-max VALU chain of tile n+1 are independent, so inside the
+// producer wave the matrix pipe and the VALU overlap instead of running one after the other.
+__device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
+                                     const int* tpre, const int* tarea, int wave, int lane, long long t_entry) {
   const BankView& b = a.b;
   const int o = blockIdx.y;
-  const int lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+  const int l15 = lane & 15, g = lane >> 4;
   const int jt0 = wk.jt0, ntl = wk.ntl;
-  int t = wk.t, lt = wk.lt;
-  // Coordinates of global tile j (>= current), clamped to the split's last tile.  Clamping makes
-  // every prefetch UNCONDITIONAL (a load past the end just re-reads the last tile): with branches
-  // around the loads hipcc cannot count them and falls back to s_waitcnt vmcnt(0), which drains the
-  // loads issued a moment ago and puts their full latency on the critical path of every tile.
-  const int jlast = jt0 + ntl - 1;
-  auto advance = [&](int& tt, int& ll, int j) {
-    j = min(j, jlast);
-    while (tpre[tt + 1] <= j) ++tt;                // skips frames with an empty box
-    ll = j - tpre[tt];
-  };
-  const size_t so0 = (size_t)o * b.Tcap;
-  const size_t tiles_per_slot = (size_t)(b.hwp / kJT);
-  // K: a tile is one contiguous 8 KB block per plane; 512 threads x 16 B.  LDS image: row = byte/256,
-  // chunk = (byte/16)&15 stored at chunk ^ (row & 15) -> conflict-free ds_read_b128 of the A fragments.
-  // Two register sets (A: even iterations, B: odd) so that two K tiles are in flight at any time.
-  half8 krA[2], krB[2];
-  auto k_load = [&](half8 (&kr)[2], int tt, int ll) {
-    const size_t off = ((so0 + tt) * b.hwp + (size_t)ll * kJT) * kDe * sizeof(_Float16) + (size_t)tid * 16;
-    kr[0] = *reinterpret_cast<const half8*>(b.kh + off);
-    kr[1] = *reinterpret_cast<const half8*>(b.kl + off);
-  };
-  const int krow = tid >> 4;
-  const int kdst = krow * 256 + (((tid & 15) ^ (krow & 15)) << 4);
-  auto k_store = [&](const half8 (&kr)[2], int buf) {
-    *reinterpret_cast<half8*>(Kl_ + buf * 2 * kKbuf + kdst) = kr[0];
-    *reinterpret_cast<half8*>(Kl_ + buf * 2 * kKbuf + kKbuf + kdst) = kr[1];
-  };
-  // V: fragment-ordered planes; this wave's first d-tile and its lane inside a tile's 32 KB plane
-  const int dt0 = PRODUCER ? BK_PDT * wave : 4 * BK_PDT + (8 - BK_PDT) * (wave - 4);
-  const size_t vlane = (size_t)(dt0 * 64 + lane) * 16;
-  auto v_tile = [&](int tt, int ll) { return ((so0 + tt) * tiles_per_slot + ll) * (size_t)(kDo * kJT * 2) + vlane; };
-  // V fragment registers: set A holds even tiles, set B odd tiles; a set is refilled with tile n+2
-  // right after PV(n) has consumed it, so every V load has two iterations to land.
-  half8 vhA[NDT], vlA[NDT], vhB[NDT], vlB[NDT];
-  f32x4 acc[NDT][4];
-#pragma unroll
-  for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-    for (int it = 0; it < 4; ++it) acc[dt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float mref = -INFINITY, lsum = 0.0f;
 #if BK_TRACE
-  long long* trc = reinterpret_cast<long long*>(a.ws_o + ((size_t)o * a.slots + (a.slots - 1)) * (size_t)kDo * kQT) + (PRODUCER ? 0 : 1024);
+  long long* trc = reinterpret_cast<long long*>(a.ws_o + ((size_t)o * a.slots + (a.slots - 1)) * (size_t)kDo * kQT);
   int trn = 0;
-  const bool trace_on = blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0;
-#define STAMP() do { if (trace_on && trn < 1000) trc[trn++] = (long long)__builtin_readcyclecounter(); } while (0)
+  const bool trace_on = blockIdx.x == 0 && wave == 0 && lane == 0;
   if (trace_on) trc[trn++] = t_entry;
-#else
-#define STAMP() do {} while (0)
 #endif
-  STAMP();
-
-  // ---- prologue: K of the first two tiles and V of the first go out first, the scattered query
-  //      loads behind them: all their latencies overlap
-  int tn = t, ltn = lt;                            // tile n+1
-  k_load(krA, t, lt);
-  advance(tn, ltn, jt0 + 1);
-  k_load(krB, tn, ltn);
-  {
-    const size_t off = v_tile(t, lt);
-#pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) {
-      vhA[dt] = *reinterpret_cast<const half8*>(b.vh + off + dt * 1024);
-      vlA[dt] = *reinterpret_cast<const half8*>(b.vl + off + dt * 1024);
-    }
-    const size_t off1 = v_tile(tn, ltn);
-#pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) {
-      vhB[dt] = *reinterpret_cast<const half8*>(b.vh + off1 + dt * 1024);
-      vlB[dt] = *reinterpret_cast<const half8*>(b.vl + off1 + dt * 1024);
-    }
-  }
+  BK_STAMP();
   // query fragments (B operand of S): lane (query l15, group g) holds channels 32ks + 8g + e
-  half8 qh[PRODUCER ? 4 : 1], ql[PRODUCER ? 4 : 1];
-  if (PRODUCER) {
+  half8 qh[4], ql[4];
+  {
     const int qn = wk.qt * kQT + wave * 16 + l15;
     const bool qvalid = qn < wk.Mq;
     int cell = 0;
@@ -330,7 +312,9 @@ __device__ inline void role_loop(const BArgs& a, const Walk& wk, char* Kl_, char
       cell = (wk.qr.cy0 + ry) * b.w + wk.qr.cx0 + (qn - ry * rw);
     }
     const float* qb = a.qk + (size_t)o * kDe * b.hw + cell;
-    const float keep = qvalid ? 1.0f : 0.0f;
+    // 1/sqrt(De) (models/rmnet.py:156) and log2(e) are folded into the query: S comes out of the
+    // MFMAs in the log2 domain and the soft-max is a bare v_exp_f32 (= 2^x) per element.
+    const float keep = qvalid ? a.qscale : 0.0f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -338,194 +322,295 @@ __device__ inline void role_loop(const BArgs& a, const Walk& wk, char* Kl_, char
         const float x = qb[(size_t)(32 * ks + 8 * g + e) * b.hw] * keep;
         _Float16 hi, lo;
         split_f16(x, hi, lo);
-        qh[PRODUCER ? ks : 0][e] = hi; ql[PRODUCER ? ks : 0][e] = lo;
+        qh[ks][e] = hi; ql[ks][e] = lo;
       }
   }
-  // ---- software pipeline (one barrier per tile):
-  //   iteration i :  all waves      PV(i)            reads P[i&1] (published by the barrier of i-1)
-  //                  producers      S(i+1), soft-max writes P[(i+1)&1]  -- one tile AHEAD of the PV
-  //                  all waves      K tile i+2 (registers, requested during i-2) -> LDS ring slot
-  //                                 (i+2)%3, then request K tile i+4 into the same registers
-  //   so the consumers never wait for the producers' soft-max, the producers' VALU phase runs under
-  //   the consumers' MFMAs, and no global-memory latency sits between a barrier and the MFMAs.
-  k_store(krA, 0);
-  k_store(krB, 1);
-  int t2 = tn, lt2 = ltn;                          // tile n+2 (in flight in set A)
-  advance(t2, lt2, jt0 + 2);
-  k_load(krA, t2, lt2);
-  int t3 = t2, lt3 = lt2;                          // tile n+3 (in flight in set B)
-  advance(t3, lt3, jt0 + 3);
-  k_load(krB, t3, lt3);
+  float mref = -INFINITY, lsum = 0.0f;
 
-  // S = K^T Q, online soft-max and P fragments of one tile (producers only)
-  auto s_phase = [&](int tt, int ll, int kslot, int pbuf) {
-    const int nvalid = tarea[tt] - ll * kJT;   // cells of this tile that exist (>= 1)
-    // Four independent accumulator chains: two MFMAs on one accumulator are >= 4 issues apart.
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+  struct Frags { half8 a0h[4], a1h[4], a0l[4], a1l[4]; };
+  auto k_frags = [&](Frags& f, int kslot) {   // 16 conflict-free ds_read_b128 (XOR-swizzled rows)
     const char* kb = Kl_ + kslot * 2 * kKbuf;
-    {   // all 16 fragment reads in flight, then the 24 MFMAs (producers have the registers for it)
-      half8 a0h[4], a1h[4], a0l[4], a1l[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int sw = ((4 * ks + g) ^ l15) << 4;
-        a0h[ks] = *reinterpret_cast<const half8*>(kb + l15 * 256 + sw);
-        a1h[ks] = *reinterpret_cast<const half8*>(kb + (16 + l15) * 256 + sw);
-        a0l[ks] = *reinterpret_cast<const half8*>(kb + kKbuf + l15 * 256 + sw);
-        a1l[ks] = *reinterpret_cast<const half8*>(kb + kKbuf + (16 + l15) * 256 + sw);
+    for (int ks = 0; ks < 4; ++ks) {
+      const int sw = ((4 * ks + g) ^ l15) << 4;
+      f.a0h[ks] = *reinterpret_cast<const half8*>(kb + l15 * 256 + sw);
+      f.a1h[ks] = *reinterpret_cast<const half8*>(kb + (16 + l15) * 256 + sw);
+      f.a0l[ks] = *reinterpret_cast<const half8*>(kb + kKbuf + l15 * 256 + sw);
+      f.a1l[ks] = *reinterpret_cast<const half8*>(kb + kKbuf + (16 + l15) * 256 + sw);
+    }
+  };
+  // S = K^T Q of one tile (log2 domain).  Two accumulator chains (cells 0-15 / 16-31), the three
+  // split terms summed inside the chain, small terms first; consecutive MFMAs alternate chains, which
+  // is all the distance a dependent 16x16x32 MFMA needs.  Lane result: S[cell 4g + r (+16)][query l15].
+  auto s_mfma = [&](const Frags& f, f32x4& s0, f32x4& s1) {
+    s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a0l[0], qh[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a1l[0], qh[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks > 0) {
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a0l[ks], qh[ks], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a1l[ks], qh[ks], s1, 0, 0, 0);
       }
+      s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a0h[ks], ql[ks], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a1h[ks], ql[ks], s1, 0, 0, 0);
+    }
 #pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) {
-        const int ks = PRODUCER ? k4 : 0;
-        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0l[k4], qh[ks], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l[k4], qh[ks], c1, 0, 0, 0);
-        s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h[k4], qh[ks], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h[k4], qh[ks], s1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h[k4], ql[ks], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h[k4], ql[ks], c1, 0, 0, 0);
+    for (int ks = 0; ks < 4; ++ks) {
+      s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a0h[ks], qh[ks], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a1h[ks], qh[ks], s1, 0, 0, 0);
+    }
+  };
+  // Online soft-max of one tile and its P fragments (k index of the fragment: e = r (+4)).
+  // While the matrix pipe is saturated by the consumers a VALU instruction of this wave issues only
+  // every ~11 cycles (trace), so the chain is kept short: no scale/log2e multiplies (folded into q),
+  // the padding mask only on a frame's last tile, packed hi conversion, lo = p - hi in one
+  // v_fma_mix per element.  nvalid = cells of this tile that exist (0 for the phantom tile past the
+  // split's end: every score is -inf then, P = 0 and the running state is untouched).
+  auto soft_max = [&](const f32x4& s0, const f32x4& s1, int nvalid, int pbuf) {
+    float sv[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+    if (nvalid < kJT) {   // wave-uniform
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sv[r] = (4 * g + r < nvalid) ? sv[r] : -INFINITY;
+        sv[4 + r] = (16 + 4 * g + r < nvalid) ? sv[4 + r] : -INFINITY;
       }
     }
-    s0 += c0;
-    s1 += c1;
-    // lane holds S[cell 4g + r (+16)][query l15]; k index of the P fragment: e = r (+4)
-    float sv[8];
-    float tmax = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      sv[r] = (4 * g + r < nvalid) ? s0[r] * a.inv_sqrt_de : -INFINITY;        // models/rmnet.py:156
-      sv[4 + r] = (16 + 4 * g + r < nvalid) ? s1[r] * a.inv_sqrt_de : -INFINITY;
-      tmax = fmaxf(tmax, fmaxf(sv[r], sv[4 + r]));
-    }
+    float tmax = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])),
+                       fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
     tmax = group4_max(tmax);
-    float alpha = 1.0f;
-    if (tmax > mref + kDefer) {        // deferred running reference (first tile: mref = -inf)
-      alpha = __expf(mref - tmax);
-      mref = tmax;
-    }
+    // deferred running reference (first tile: mref = -inf): bump only when exceeded by > kDefer
+    const bool bump = tmax > mref + kDeferLog2;
+    const float alpha = bump ? __builtin_amdgcn_exp2f(mref - tmax) : 1.0f;
+    mref = bump ? tmax : mref;
+    float pv[8];
     float rs = 0.0f;
-    half8 ph, plo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float pv = __expf(sv[e] - mref);   // in [0, e^8]: no saturation needed for the split
-      rs += pv;
-      const _Float16 hi = (_Float16)pv;
-      ph[e] = hi;
-      plo[e] = (_Float16)(pv - (float)hi);
+      pv[e] = __builtin_amdgcn_exp2f(sv[e] - mref);   // in [0, e^8]: no saturation needed for the split
+      rs += pv[e];
     }
     rs = group4_sum(rs);
     lsum = lsum * alpha + rs;
-    char* pb = Pl_ + ((pbuf * 4 + wave) * 2) * 1024 + lane * 16;
-    *reinterpret_cast<half8*>(pb) = ph;
-    *reinterpret_cast<half8*>(pb + 1024) = plo;
-    if (g == 0) Al[pbuf * kQT + wave * 16 + l15] = alpha;
-  };
-
-  __syncthreads();                                   // K tiles 0 and 1 visible
-  if (PRODUCER && BK_ABLATE != 3) s_phase(t, lt, 0, 0);
-  __syncthreads();                                   // P(0) visible
-  STAMP();
-
-  int ks1 = 1, ks2 = 2;                              // ring slots of tiles n+1 and n+2
-  auto iteration = [&](const int it_, half8 (&kr)[2], half8 (&vh)[NDT], half8 (&vl)[NDT]) {
-    const int buf = it_ & 1;
-    STAMP();   // loop top
-    const bool has_next = it_ + 1 < ntl;
-    // ---- O += V P for this wave's NDT d-tiles x 64 queries (tile n)
-    {
-      const size_t noff = v_tile(t2, lt2);   // refill target: tile n+2 (clamped past the end)
-      const char* nvh = b.vh + noff;
-      const char* nvl = b.vl + noff;
-      const char* pfr = Pl_ + (buf * 4) * 2048;
-      float al[4];
+    u32x4 ph, plo;
 #pragma unroll
-      for (int it = 0; it < 4; ++it) al[it] = Al[buf * kQT + it * 16 + l15];
-      // P fragments are consumed one query tile at a time (16 registers live instead of 32); the
-      // NDT accumulators touched between two uses of the same accumulator keep the MFMAs independent.
-      half8 bh = *reinterpret_cast<const half8*>(pfr + lane * 16);
-      half8 bl = *reinterpret_cast<const half8*>(pfr + 1024 + lane * 16);
-      if (__any(al[0] != 1.0f || al[1] != 1.0f || al[2] != 1.0f || al[3] != 1.0f)) {
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-          for (int it = 0; it < 4; ++it) acc[dt][it] *= al[it];
-      }
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const half8 ch = bh, cl = bl;
-        if (it < 3) {   // next query tile's fragments: their LDS latency hides under this tile's MFMAs
-          bh = *reinterpret_cast<const half8*>(pfr + (it + 1) * 2048 + lane * 16);
-          bl = *reinterpret_cast<const half8*>(pfr + (it + 1) * 2048 + 1024 + lane * 16);
-        }
-#if BK_ABLATE != 2
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
-          acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[dt], ch, acc[dt][it], 0, 0, 0);
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
-          acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[dt], cl, acc[dt][it], 0, 0, 0);
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
-          acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[dt], ch, acc[dt][it], 0, 0, 0);
-#endif
-      }
-      if (BK_ABLATE != 1) {   // refill this set with tile n+2 (two tiles ahead), unconditionally
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-          vh[dt] = *reinterpret_cast<const half8*>(nvh + dt * 1024);
-          vl[dt] = *reinterpret_cast<const half8*>(nvl + dt * 1024);
-        }
-      }
+    for (int i = 0; i < 4; ++i) {
+      const half2 h = {(_Float16)pv[2 * i], (_Float16)pv[2 * i + 1]};
+      const unsigned hk = __builtin_bit_cast(unsigned, h);
+      unsigned lk;   // lo = fp16(p - hi): fp32 subtract and one rounding, straight into its half
+      asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lk) : "v"(pv[2 * i]), "v"(hk));
+      asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lk) : "v"(pv[2 * i + 1]), "v"(hk));
+      ph[i] = hk;
+      plo[i] = lk;
     }
-    STAMP();   // PV done
-    // ---- producers: S and soft-max of tile n+1 (its K tile became visible with the last barrier).
-    //      (Doing this BEFORE the producers' own PV share was measured 4 % slower.)
-    if (PRODUCER && has_next && BK_ABLATE != 3) s_phase(tn, ltn, ks1, buf ^ 1);
-    STAMP();   // S/soft-max done
-    // ---- K ring: tile n+2 (requested two iterations ago) -> slot ks2; request tile n+4 into the
-    //      same registers (the other set holds tile n+3, still in flight)
-    int t4 = t3, lt4 = lt3;
-    k_store(kr, ks2);                                // (a clamped duplicate past the end: harmless)
-    advance(t4, lt4, jt0 + it_ + 4);
-    k_load(kr, t4, lt4);
-    STAMP();   // before barrier
-    __syncthreads();   // the one barrier per tile
-    STAMP();   // after barrier
-    t = tn; lt = ltn;
-    tn = t2; ltn = lt2;
-    t2 = t3; lt2 = lt3;
-    t3 = t4; lt3 = lt4;
-    ks1 = ks2;
-    ks2 = ks2 == 2 ? 0 : ks2 + 1;
+    char* pb = Pl_ + pbuf * kPbuf + wave * 2048 + lane * 16;
+    *reinterpret_cast<u32x4*>(pb) = ph;
+    *reinterpret_cast<u32x4*>(pb + 1024) = plo;
+    if (g == 0) Al[pbuf * kQT + l15 * 4 + wave] = alpha;
   };
-  for (int it_ = 0; it_ < ntl; it_ += 2) {
-    iteration(it_, krA, vhA, vlA);
-    if (it_ + 1 < ntl) iteration(it_ + 1, krB, vhB, vlB);
-  }
-  STAMP();
 
-  // ---- partial (O, m, l) -> workspace slot L, layout [query][channel] (16-byte stores)
-  float* wo = a.ws_o + ((size_t)o * a.slots + wk.L) * (size_t)kDo * kQT;
-#pragma unroll
-  for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-    for (int it = 0; it < 4; ++it)
-      *reinterpret_cast<f32x4*>(wo + (size_t)(it * 16 + l15) * kDo + (dt0 + dt) * 16 + 4 * g) = acc[dt][it];
-  if (PRODUCER && g == 0) {
+  Cursor cs;                       // tile whose soft-max comes next
+  cs.init(tpre, wk.t, jt0 + ntl - 1);
+  f32x4 sp0, sp1;                  // S of the tile after it (computed one iteration earlier)
+  Frags f;
+  __syncthreads();                                   // A: K tiles 0..3 in LDS
+  if (!(BK_ABLATE & 4)) {
+    f32x4 s0, s1;
+    k_frags(f, 0);
+    s_mfma(f, s0, s1);
+    k_frags(f, 1);
+    s_mfma(f, sp0, sp1);
+    const int l0 = cs.seek(jt0);
+    soft_max(s0, s1, tarea[cs.tt] - l0 * kJT, 0);
+    k_frags(f, 2);                                   // for the MFMAs of iteration 0
+  }
+  __syncthreads();                                   // B: P(0) visible
+  BK_STAMP();
+  int kslot = 3;                                     // ring slot of tile n+3
+  for (int n = 0; n < ntl; ++n) {
+    BK_STAMP();   // loop top
+    if (!(BK_ABLATE & 4)) {
+      const int l1 = cs.seek(jt0 + n + 1);
+      const int nvalid = n + 1 < ntl ? tarea[cs.tt] - l1 * kJT : 0;
+      f32x4 s0, s1;
+      s_mfma(f, s0, s1);                             // tile n+2 (fragments read before the barrier)
+#if BK_SCHED == 1
+      __builtin_amdgcn_sched_barrier(0);             // MFMAs first (the pipe is idle right after a barrier)
+#endif
+      BK_STAMP();   // MFMAs issued
+      soft_max(sp0, sp1, nvalid, (n + 1) & 1);       // tile n+1
+      BK_STAMP();   // soft-max done
+      sp0 = s0; sp1 = s1;
+      k_frags(f, kslot);                             // tile n+3: its LDS latency hides under the barrier
+    }
+    kslot = (kslot + 1) & 3;
+    BK_STAMP();   // S/soft-max done
+    __syncthreads();
+    BK_STAMP();   // after barrier
+  }
+  if (g == 0 && !(BK_ABLATE & 8)) {
     float* wm = a.ws_ml + ((size_t)o * a.slots + wk.L) * 2 * kQT;
     wm[wave * 16 + l15] = mref;
     wm[kQT + wave * 16 + l15] = lsum;
   }
+  BK_STAMP();
+}
+
+// ---------------------------------------------------------------- consumers: O += V P, K ring
+__device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
+                                     const int* tpre, int wave, int lane, long long t_entry) {
+  const BankView& b = a.b;
+  const int o = blockIdx.y;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int jt0 = wk.jt0, ntl = wk.ntl;
+  const size_t so0 = (size_t)o * b.Tcap;
+  const size_t tiles_per_slot = (size_t)(b.hwp / kJT);
+#if BK_TRACE
+  long long* trc = reinterpret_cast<long long*>(a.ws_o + ((size_t)o * a.slots + (a.slots - 1)) * (size_t)kDo * kQT) + 1024;
+  int trn = 0;
+  const bool trace_on = blockIdx.x == 0 && wave == kProducers && lane == 0;
+  if (trace_on) trc[trn++] = t_entry;
+#endif
+  BK_STAMP();
+  // K: a tile is one contiguous 8 KB block per plane = 512 consumer threads x 16 B.  LDS image:
+  // row = cell (256 B), 16-byte chunk c of row r stored at chunk c ^ (r & 15) -> the producers'
+  // ds_read_b128 of the A fragments are conflict-free.
+  const int ct = (wave - kProducers) * 64 + lane;
+  const int krow = ct >> 4;
+  const int kdst = krow * 256 + (((ct & 15) ^ (krow & 15)) << 4);
+  auto k_load = [&](half8 (&kr)[2], int tt, int ll) {
+    const size_t off = ((so0 + tt) * b.hwp + (size_t)ll * kJT) * kDe * sizeof(_Float16) + (size_t)ct * 16;
+    kr[0] = *reinterpret_cast<const half8*>(b.kh + off);
+    kr[1] = *reinterpret_cast<const half8*>(b.kl + off);
+  };
+  auto k_store = [&](const half8 (&kr)[2], int slot) {
+    *reinterpret_cast<half8*>(Kl_ + slot * 2 * kKbuf + kdst) = kr[0];
+    *reinterpret_cast<half8*>(Kl_ + slot * 2 * kKbuf + kKbuf + kdst) = kr[1];
+  };
+  // V: fragment-ordered planes; this wave's first d-tile and its lane inside a tile's 32 KB plane
+  const int dt0 = kCDT * (wave - kProducers);
+  const size_t vlane = (size_t)(dt0 * 64 + lane) * 16;
+  auto v_tile = [&](int tt, int ll) { return ((so0 + tt) * tiles_per_slot + ll) * (size_t)(kDo * kJT * 2) + vlane; };
+  // V fragment registers: ONE set.  The PV loop is channel-tile-major, so the fragments of channel
+  // tile dt are dead after its 12 MFMAs and are refilled with the NEXT tile right there: the 8 + 2
+  // loads of a tile are spread over the whole PV phase (issued together after the PV, the 80 loads
+  // of the 8 consumers queue up in the CU's one address unit, 16 cycles each, while the matrix pipe
+  // idles: that serial tail was 1/3 of a tile) and every load has one full iteration to land.
+  half8 vh[kCDT], vl[kCDT];
+  half8 kr[2];                     // K tile n+5 on its way to the ring (one iteration to land)
+  Cursor ck, cv;
+  ck.init(tpre, wk.t, jt0 + ntl - 1);
+  cv.init(tpre, wk.t, jt0 + ntl - 1);
+  {
+    half8 k0[2], k1[2], k2[2], k3[2];
+    const int a0 = ck.seek(jt0);
+    k_load(k0, ck.tt, a0);
+    const int a1 = ck.seek(jt0 + 1);
+    k_load(k1, ck.tt, a1);
+    const int a2 = ck.seek(jt0 + 2);
+    k_load(k2, ck.tt, a2);
+    const int a3 = ck.seek(jt0 + 3);
+    k_load(k3, ck.tt, a3);
+    // same issue order as the steady state (K request, then the V fragments), so that the loop's
+    // counted waits are the same on entry as on the back edge
+    const int a4 = ck.seek(jt0 + 4);
+    k_load(kr, ck.tt, a4);
+    const int l0 = cv.seek(jt0);
+    const size_t off = v_tile(cv.tt, l0);
+#pragma unroll
+    for (int dt = 0; dt < kCDT; ++dt) {
+      vh[dt] = *reinterpret_cast<const half8*>(b.vh + off + dt * 1024);
+      vl[dt] = *reinterpret_cast<const half8*>(b.vl + off + dt * 1024);
+    }
+    k_store(k0, 0);
+    k_store(k1, 1);
+    k_store(k2, 2);
+    k_store(k3, 3);
+  }
+  f32x4 acc[kCDT][4];
+#pragma unroll
+  for (int dt = 0; dt < kCDT; ++dt)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) acc[dt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();                                   // A: K tiles 0..3 visible
+  __syncthreads();                                   // B: P(0) visible
+  BK_STAMP();
+
+  int kslot = 0;                                     // ring slot of tile n+4 (= n % 4)
+  for (int n = 0; n < ntl; ++n) {
+    const int buf = n & 1;
+    BK_STAMP();   // loop top
+    const char* pfr = Pl_ + buf * kPbuf;
+    const f32x4 al = *reinterpret_cast<const f32x4*>(Al + buf * kQT + l15 * 4);
+    half8 bh[4], bl[4];                              // all P fragments of this tile
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      bh[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + lane * 16);
+      bl[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + 1024 + lane * 16);
+    }
+    // K ring: tile n+4 (requested one iteration ago) -> slot n%4; request tile n+5
+    if (!(BK_ABLATE & 16)) {
+      k_store(kr, kslot);                            // (a clamped duplicate past the end: harmless)
+      const int l5 = ck.seek(jt0 + n + 5);
+      k_load(kr, ck.tt, l5);
+    }
+    kslot = (kslot + 1) & 3;
+    const int l1 = cv.seek(jt0 + n + 1);             // refill source: tile n+1 (clamped past the end)
+    const size_t noff = v_tile(cv.tt, l1);
+    const char* nvh = b.vh + noff;
+    const char* nvl = b.vl + noff;
+    if (__any(al[0] != 1.0f || al[1] != 1.0f || al[2] != 1.0f || al[3] != 1.0f)) {
+#pragma unroll
+      for (int dt = 0; dt < kCDT; ++dt)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) acc[dt][it] *= al[it];
+    }
+    // ---- O += V P: 4 channel tiles x 4 query tiles x 3 split terms; the 4 query tiles between two
+    //      uses of an accumulator keep the MFMAs independent
+#pragma unroll
+    for (int dt = 0; dt < kCDT; ++dt) {
+#if !(BK_ABLATE & 2)
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[dt], bh[it], acc[dt][it], 0, 0, 0);
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[dt], bl[it], acc[dt][it], 0, 0, 0);
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[dt], bh[it], acc[dt][it], 0, 0, 0);
+#endif
+      if (!(BK_ABLATE & 1)) {   // this channel tile's fragments of the next tile, unconditionally
+        vh[dt] = *reinterpret_cast<const half8*>(nvh + dt * 1024);
+        vl[dt] = *reinterpret_cast<const half8*>(nvl + dt * 1024);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE (the scheduler sinks them to the end)
+    }
+    BK_STAMP();   // PV done
+    __syncthreads();   // the one barrier per tile
+    BK_STAMP();   // after barrier
+  }
+  BK_STAMP();
+
+  // ---- partial O -> workspace slot L in fragment order (common.h): 1 KB contiguous per store
+  if (!(BK_ABLATE & 8)) {
+    float* wo = a.ws_o + ((size_t)o * a.slots + wk.L) * (size_t)kDo * kQT;
+#pragma unroll
+    for (int dt = 0; dt < kCDT; ++dt)
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        *reinterpret_cast<f32x4*>(wo + partial_frag_offset(dt0 + dt, it, lane)) = acc[dt][it];
+  }
 #if BK_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-  STAMP();   // epilogue stores drained
+  BK_STAMP();   // epilogue stores drained
 }
 
-__global__ __launch_bounds__(kRThreads, 2) void bk_main(const BArgs a) {
+__global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
   char* Kl_ = lds;                                 // [ring slot][plane][8 KB]
-  char* Pl_ = lds + 6 * kKbuf;                     // [buf][ntile][plane][lane*16]
-  float* Al = reinterpret_cast<float*>(Pl_ + 2 * 4 * 2 * 64 * 16);
+  char* Pl_ = lds + 8 * kKbuf;                     // [buf][ntile][plane][lane*16]
+  float* Al = reinterpret_cast<float*>(Pl_ + 2 * kPbuf);
   int* tpre = reinterpret_cast<int*>(Al + 2 * kQT);
   int* tarea = tpre + kMaxT + 4;
 
@@ -533,10 +618,7 @@ __global__ __launch_bounds__(kRThreads, 2) void bk_main(const BArgs a) {
   const BankView& b = a.b;
   const int tid = threadIdx.x, o = blockIdx.y;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool producer = wave < 4;
-#ifndef BK_PRIO
-#define BK_PRIO 2
-#endif
+  const bool producer = wave < kProducers;
   if (producer && BK_PRIO > 0) __builtin_amdgcn_s_setprio(BK_PRIO);
 
   // ---- plan: tile prefix over the T memorised frames, query rectangle, split decode.  The query
@@ -592,12 +674,12 @@ __global__ __launch_bounds__(kRThreads, 2) void bk_main(const BArgs a) {
       if (tpre[mid] <= wk.jt0) lo = mid; else hi = mid;
     }
     wk.t = lo;
-    wk.lt = wk.jt0 - tpre[lo];
   }
+  const int lane = tid & 63;
   if (producer)
-    role_loop<true>(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, tid, t_entry);
+    producer_loop(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, lane, t_entry);
   else
-    role_loop<false>(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, tid, t_entry);
+    consumer_loop(a, wk, Kl_, Pl_, Al, tpre, wave, lane, t_entry);
 }
 
 }  // namespace
@@ -618,7 +700,7 @@ int launch_bank_main(const BankReadArgs& m, hipStream_t st) {
   a.qk = m.qk; a.qv = m.qv; a.qry_rects = m.qry_rects;
   a.ws_o = m.ws_o; a.ws_ml = m.ws_ml; a.ws_plan = m.ws_plan;
   a.T = m.T; a.slots = m.slots;
-  a.inv_sqrt_de = 1.0f / sqrtf((float)kDe);
+  a.qscale = 1.44269504088896341f / sqrtf((float)kDe);
   hipLaunchKernelGGL(bk_main, dim3(m.slots, m.no), dim3(kRThreads), 0, st, a);
   return check_launch();
 }

@@ -66,6 +66,17 @@ int launch_rect_mask(const float* x, int n, int C, int T, int h, int w, const in
 int launch_flow_affine(const float* flow, const float* m1, const float* m2, int H, int W,
                        float* out, hipStream_t st);
 
+// Split partials in the workspace: per (object, slot) a [32 channel tiles][4 query tiles][64 lanes][4]
+// fp32 block = the 16x16 MFMA accumulator fragments exactly as they sit in registers
+// (lane = 16 * ((channel % 16) / 4) + query % 16, element = channel % 4).  A wave stores 1 KB
+// contiguous per fragment and the combine kernel reads whole fragments back (16 B per lane).
+__host__ __device__ inline size_t partial_frag_offset(int dtile, int qtile, int lane) {
+  return ((size_t)(dtile * 4 + qtile) * 64 + lane) * 4;
+}
+__host__ __device__ inline size_t partial_elem_offset(int query, int channel) {
+  return partial_frag_offset(channel >> 4, query >> 4, 16 * ((channel & 15) >> 2) + (query & 15)) + (channel & 3);
+}
+
 struct MemReadArgs {
   const float *mk, *mv, *qk, *qv;
   float* out;

@@ -65,7 +65,7 @@ struct KArgs {
   float* out;
   const int32_t* mem_rects;  // [no][T][4] or null
   const int32_t* qry_rects;  // [no][4] or null
-  float* ws_o;               // [no][slots][kDo][kQT]
+  float* ws_o;               // [no][slots] partial blocks in fragment order (common.h)
   float* ws_ml;              // [no][slots][2][kQT]
   int32_t* ws_plan;          // [no][kPlanInts], written by block 0 of the read kernel
   int no, T, h, w, hw;
@@ -328,14 +328,13 @@ __global__ __launch_bounds__(kThreads, 1) void mr_main(const KArgs a) {
     }
   }
 
-  // ---- partial (O, m, l) -> workspace slot L, layout [query][channel]: a lane owns 4 consecutive
-  //      channels of one query, so every store is 16 bytes and a lane group fills 64 contiguous bytes
+  // ---- partial (O, m, l) -> workspace slot L in fragment order (common.h): 1 KB contiguous per store
   float* wo = a.ws_o + ((size_t)o * a.slots + L) * (size_t)kDo * kQT;
 #pragma unroll
   for (int dt = 0; dt < 8; ++dt)
 #pragma unroll
     for (int it = 0; it < 4; ++it)
-      *reinterpret_cast<f32x4*>(wo + (size_t)(it * 16 + l15) * kDo + wave * 128 + dt * 16 + 4 * g) = acc[dt][it];
+      *reinterpret_cast<f32x4*>(wo + partial_frag_offset(wave * 8 + dt, it, lane)) = acc[dt][it];
   if (g == 0) {
     float* wm = a.ws_ml + ((size_t)o * a.slots + L) * 2 * kQT;
     wm[wave * 16 + l15] = mref;
@@ -343,24 +342,31 @@ __global__ __launch_bounds__(kThreads, 1) void mr_main(const KArgs a) {
   }
 }
 
-constexpr int kCombCh = 16;  // read-out channels (and as many q_val channels) per combine block
+#ifndef RMNET_COMB_CH
+#define RMNET_COMB_CH 64
+#endif
+constexpr int kCombCh = RMNET_COMB_CH;  // read-out channels (and as many q_val channels) per combine block
+constexpr int kCombDt = kCombCh / 16;    // = channel tiles (fragments) per query tile and split
 
-// Merge the per-split partials (workspace layout [slot][query][channel]).
+// Merge the per-split partials (fragment-ordered blocks, common.h).
 // grid = (nqt_max + cell tiles, kDo / kCombCh, no).  The plan comes from the 32-byte record the read
 // kernel left behind (one load instead of re-deriving it).
-//   blocks [0, nqt_max)   : one compacted query tile x 16 channels each (exit beyond the live tiles):
+//   blocks [0, nqt_max)   : one compacted query tile x 64 channels each (exit beyond the live tiles):
 //        4 lanes per query build the split weights w[s][q] = exp(m_s - m_tot) / l_tot (with the
-//        closed-form N_out * exp(-m_tot) term of the masked memory cells); then thread
-//        (channel, query group) accumulates 4 queries x nsplit partials with 32 independent loads in
-//        flight, the 64 x 16 tile goes through LDS and is written to the queries' cells coalesced
-//        along cells, together with the q_val half of the cat (models/rmnet.py:163).
+//        closed-form N_out * exp(-m_tot) term of the masked memory cells); the 64 channels of a
+//        split are ONE contiguous 16 KB run of fragments, read with 16-byte loads (a thread owns
+//        the same query in all of them, so one weight per split), 16 loads in flight; the 64 x 64
+//        tile goes through LDS and is written to the queries' cells coalesced along cells,
+//        together with the q_val half of the cat (models/rmnet.py:163).
 //   blocks [nqt_max, ...) : one tile of 64 grid cells each; cells OUTSIDE the query box get the
 //        mean-slot vector (uniform soft-max, see file header) and q_val * 0.  Skipped when dense.
+// The bank kernel keeps its running reference in the log2 domain (2^x soft-max), mr_main in the
+// natural one; a.bank_area tells which.
 template <bool REGIONAL>
 __global__ __launch_bounds__(kThreads) void mr_combine(const KArgs a, int nqt_max) {
   __shared__ float Wt[kMaxSplits][kQT];
   __shared__ float red[4][kQT];
-  __shared__ float Tt[kQT][kCombCh + 1];
+  __shared__ float Tt[kCombCh][kQT + 1];
   const int tid = threadIdx.x, o = blockIdx.z;
   Plan pl;
   {
@@ -369,6 +375,7 @@ __global__ __launch_bounds__(kThreads) void mr_combine(const KArgs a, int nqt_ma
     pl.qr = Rect{pr[4], pr[5], pr[6], pr[7]};
     pl.njt = 0;
   }
+  const bool log2d = a.bank_area != nullptr;
   const int qi = tid & 63, sl = tid >> 6;
   const float n_out = (float)(a.T * a.hw - pl.M);
   const float* __restrict__ ml = a.ws_ml + (size_t)o * a.slots * 2 * kQT;
@@ -377,6 +384,14 @@ __global__ __launch_bounds__(kThreads) void mr_combine(const KArgs a, int nqt_ma
   const int qt = fill ? (pl.Mq >> 6) : (int)blockIdx.x;
   if (!fill && qt >= pl.nqt) return;
   if (fill && (!REGIONAL || pl.Mq >= a.hw)) return;   // nothing is masked
+  if (fill) {   // a tile with no masked cell has nothing to do: skip the weights too
+    const int c0 = ((int)blockIdx.x - nqt_max) * kQT, c1 = min(c0 + kQT, a.hw) - 1;
+    const int y0 = c0 / a.w, y1 = c1 / a.w;
+    const bool inside = pl.qr.cx0 == 0 && pl.qr.cx1 == a.w - 1 ? (y0 >= pl.qr.cy0 && y1 <= pl.qr.cy1)
+                        : (y0 == y1 && y0 >= pl.qr.cy0 && y0 <= pl.qr.cy1 &&
+                           c0 - y0 * a.w >= pl.qr.cx0 && c1 - y1 * a.w <= pl.qr.cx1);
+    if (inside) return;
+  }
 
   // ---- split weights for the 64 queries of tile qt
   float mloc = -INFINITY;
@@ -389,14 +404,14 @@ __global__ __launch_bounds__(kThreads) void mr_combine(const KArgs a, int nqt_ma
   float lloc = 0.0f;
   for (int s = sl; s < pl.nsplit; s += 4) {
     const float* e = ml + ((size_t)(s * pl.nqt + qt) * 2) * kQT;
-    const float wgt = expf(e[qi] - mtot);
+    const float wgt = log2d ? exp2f(e[qi] - mtot) : expf(e[qi] - mtot);
     Wt[s][qi] = wgt;
     lloc += e[kQT + qi] * wgt;
   }
   red[sl][qi] = lloc;
   __syncthreads();
   float ltot = red[0][qi] + red[1][qi] + red[2][qi] + red[3][qi];
-  if (n_out > 0.0f) ltot += n_out * expf(-mtot);
+  if (n_out > 0.0f) ltot += n_out * (log2d ? exp2f(-mtot) : expf(-mtot));
   const float inv = 1.0f / ltot;
   for (int s = sl; s < pl.nsplit; s += 4) Wt[s][qi] *= inv;
   __syncthreads();
@@ -404,29 +419,38 @@ __global__ __launch_bounds__(kThreads) void mr_combine(const KArgs a, int nqt_ma
   const int d0 = blockIdx.y * kCombCh;
   const size_t sstride = (size_t)pl.nqt * kDo * kQT;   // between the splits of one query tile
   if (!fill) {
-    {  // accumulate: thread = (channel di, query group qs), queries qs + 16k
-      const int di = tid & 15, qs = tid >> 4;
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
-      const float* __restrict__ src = wo + (size_t)qt * kDo * kQT + d0 + di;
+    {  // accumulate: thread = (query tile it = sl, lane qi) of the 4 channel tiles of this block
+      const int q = sl * 16 + (qi & 15), gg = qi >> 4;
+      f32x4 acc[kCombDt];
+#pragma unroll
+      for (int k = 0; k < kCombDt; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* __restrict__ src = wo + (size_t)qt * kDo * kQT + partial_frag_offset(d0 >> 4, sl, qi);
+      constexpr int kU = 16 / kCombDt;       // splits per batch: 16 independent 16-byte loads in flight
       int s = 0;
-      for (; s + 8 <= pl.nsplit; s += 8) {   // 32 independent loads in flight per thread
-        float v[8][4];
+      for (; s + kU <= pl.nsplit; s += kU) {
+        f32x4 v[kU][kCombDt];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < kU; ++u)
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[u][k] = src[(size_t)(s + u) * sstride + (size_t)(qs + 16 * k) * kDo];
+          for (int k = 0; k < kCombDt; ++k)
+            v[u][k] = *reinterpret_cast<const f32x4*>(src + (size_t)(s + u) * sstride + (size_t)k * 1024);
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < kU; ++u) {
+          const float wgt = Wt[s + u][q];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) acc[k] += Wt[s + u][qs + 16 * k] * v[u][k];
+          for (int k = 0; k < kCombDt; ++k) acc[k] += wgt * v[u][k];
+        }
       }
       for (; s < pl.nsplit; ++s) {
+        const float wgt = Wt[s][q];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          acc[k] += Wt[s][qs + 16 * k] * src[(size_t)s * sstride + (size_t)(qs + 16 * k) * kDo];
+        for (int k = 0; k < kCombDt; ++k)
+          acc[k] += wgt * *reinterpret_cast<const f32x4*>(src + (size_t)s * sstride + (size_t)k * 1024);
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) Tt[qs + 16 * k][di] = acc[k];
+      for (int k = 0; k < kCombDt; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tt[k * 16 + 4 * gg + r][q] = acc[k][r];
     }
     __syncthreads();
     const int n = qt * kQT + qi;
@@ -434,20 +458,20 @@ __global__ __launch_bounds__(kThreads) void mr_combine(const KArgs a, int nqt_ma
     const int cell = REGIONAL ? query_cell(pl, a.w, n) : n;
     float* __restrict__ out = a.out + (size_t)o * 2 * kDo * a.hw + cell;
     const float* __restrict__ qv = a.qv + (size_t)o * kDo * a.hw + cell;
-#pragma unroll
+#pragma unroll 8
     for (int dd = sl; dd < kCombCh; dd += 4) {
       const int d = d0 + dd;
-      out[(size_t)d * a.hw] = Tt[qi][dd];
+      out[(size_t)d * a.hw] = Tt[dd][qi];
       out[(size_t)(kDo + d) * a.hw] = qv[(size_t)d * a.hw];          // cat(mem, q_val), :163
     }
   } else {
     // mean-slot vector for this block's channels -> LDS, then broadcast to the masked cells
     const int mq = pl.Mq & 63;
     if (tid < kCombCh) {
-      const float* __restrict__ src = wo + ((size_t)qt * kQT + mq) * kDo + d0 + tid;
+      const float* __restrict__ src = wo + (size_t)qt * kDo * kQT + partial_elem_offset(mq, d0 + tid);
       float acc = 0.0f;
       for (int s = 0; s < pl.nsplit; ++s) acc += Wt[s][mq] * src[(size_t)s * sstride];
-      Tt[0][tid] = acc;
+      Tt[tid][0] = acc;
     }
     __syncthreads();
     const int cell = ((int)blockIdx.x - nqt_max) * kQT + qi;
@@ -456,10 +480,10 @@ __global__ __launch_bounds__(kThreads) void mr_combine(const KArgs a, int nqt_ma
     if (pl.qr.contains(cy, cx)) return;              // written by the query-tile blocks
     float* __restrict__ out = a.out + (size_t)o * 2 * kDo * a.hw + cell;
     const float* __restrict__ qv = a.qv + (size_t)o * kDo * a.hw + cell;
-#pragma unroll
+#pragma unroll 8
     for (int dd = sl; dd < kCombCh; dd += 4) {
       const int d = d0 + dd;
-      out[(size_t)d * a.hw] = Tt[0][dd];
+      out[(size_t)d * a.hw] = Tt[dd][0];
       out[(size_t)(kDo + d) * a.hw] = qv[(size_t)d * a.hw] * 0.0f;   // q_val * box (:358), x*0 semantics
     }
   }

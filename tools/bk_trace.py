@@ -27,15 +27,17 @@ torch.cuda.synchronize()
 slots = 256
 off = (slots - 1) * 512 * 64 * 4
 tr = ws[off:off + 2048 * 8].view(torch.int64).cpu().numpy()
-for name, a in (('producer wave0', tr[:1024]), ('consumer wave4', tr[1024:2048])):
+for name, a, labels in (('producer wave0', tr[:1024], ['top->MFMAs issued', 'soft-max', 'K frags', 'barrier', '->next top']),
+                        ('consumer wave4', tr[1024:2048], ['top->PV done', 'barrier', '->next top'])):
     a = a[a != 0]
     d = np.diff(a)
     print(name, 'n stamps', len(a), 'total', a[-1] - a[0])
-    print('  all deltas' if len(d) < 40 else '  first 12 deltas', d[:40] if len(d) < 40 else d[:12])
-    per = 5
-    nfull = min(20, (len(d) - 4) // per)
+    print('  first deltas', d[:14])
+    per = len(labels)
+    nfull = min(40, (len(d) - 6) // per)
     if nfull < 1:
         continue
     body = d[3:3 + per * nfull].reshape(-1, per)
-    print('  labels:', ['top->PV done', 'S+softmax', 'K ring', 'barrier', '->next top'])
+    print('  labels:', labels)
     print('  per-iteration deltas (mean over its):', body.mean(0).round(0), 'sum', body.mean(0).sum())
+    print('  tail deltas', d[-4:])
