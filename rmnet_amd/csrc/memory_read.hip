@@ -343,7 +343,7 @@ __global__ __launch_bounds__(kThreads, 1) void mr_main(const KArgs a) {
 }
 
 #ifndef RMNET_COMB_CH
-#define RMNET_COMB_CH 64
+#define RMNET_COMB_CH 16
 #endif
 constexpr int kCombCh = RMNET_COMB_CH;  // read-out channels (and as many q_val channels) per combine block
 constexpr int kCombDt = kCombCh / 16;    // = channel tiles (fragments) per query tile and split
@@ -356,17 +356,21 @@ constexpr int kCombDt = kCombCh / 16;    // = channel tiles (fragments) per quer
 //        closed-form N_out * exp(-m_tot) term of the masked memory cells); the 64 channels of a
 //        split are ONE contiguous 16 KB run of fragments, read with 16-byte loads (a thread owns
 //        the same query in all of them, so one weight per split), 16 loads in flight; the 64 x 64
-//        tile goes through LDS and is written to the queries' cells coalesced along cells,
-//        together with the q_val half of the cat (models/rmnet.py:163).
-//   blocks [nqt_max, ...) : one tile of 64 grid cells each; cells OUTSIDE the query box get the
-//        mean-slot vector (uniform soft-max, see file header) and q_val * 0.  Skipped when dense.
+//        tile goes through LDS.  The block then writes a CONTIGUOUS range of grid cells: its
+//        queries' cells and the masked cells lying between them in raster order (those get the
+//        mean-slot vector -- uniform soft-max, see file header -- and q_val * 0), so that every
+//        output line has one writer; with them goes the q_val half of the cat (models/rmnet.py:163).
+//   blocks [nqt_max, ...) : one tile of 64 grid cells each, for the rows ABOVE and BELOW the query
+//        box only (mean-slot vector, q_val * 0).  Skipped when nothing is masked.
 // The bank kernel keeps its running reference in the log2 domain (2^x soft-max), mr_main in the
 // natural one; a.bank_area tells which.
 template <bool REGIONAL>
 __global__ __launch_bounds__(kThreads) void mr_combine(const KArgs a, int nqt_max) {
   __shared__ float Wt[kMaxSplits][kQT];
+  __shared__ float Wm[kMaxSplits];
   __shared__ float red[4][kQT];
   __shared__ float Tt[kCombCh][kQT + 1];
+  __shared__ float Tm[kCombCh];
   const int tid = threadIdx.x, o = blockIdx.z;
   Plan pl;
   {
@@ -380,21 +384,101 @@ __global__ __launch_bounds__(kThreads) void mr_combine(const KArgs a, int nqt_ma
   const float n_out = (float)(a.T * a.hw - pl.M);
   const float* __restrict__ ml = a.ws_ml + (size_t)o * a.slots * 2 * kQT;
   const float* __restrict__ wo = a.ws_o + (size_t)o * a.slots * (size_t)kDo * kQT;
-  const bool fill = (int)blockIdx.x >= nqt_max;   // masked-cell filler block
-  const int qt = fill ? (pl.Mq >> 6) : (int)blockIdx.x;
+  const bool fill = (int)blockIdx.x >= nqt_max;   // masked-row filler block
+  const bool masked = REGIONAL && pl.Mq < a.hw;   // some query cell is masked: a mean slot exists
+  const int qt = (int)blockIdx.x;
   if (!fill && qt >= pl.nqt) return;
-  if (fill && (!REGIONAL || pl.Mq >= a.hw)) return;   // nothing is masked
-  if (fill) {   // a tile with no masked cell has nothing to do: skip the weights too
-    const int c0 = ((int)blockIdx.x - nqt_max) * kQT, c1 = min(c0 + kQT, a.hw) - 1;
-    const int y0 = c0 / a.w, y1 = c1 / a.w;
-    const bool inside = pl.qr.cx0 == 0 && pl.qr.cx1 == a.w - 1 ? (y0 >= pl.qr.cy0 && y1 <= pl.qr.cy1)
-                        : (y0 == y1 && y0 >= pl.qr.cy0 && y0 <= pl.qr.cy1 &&
-                           c0 - y0 * a.w >= pl.qr.cx0 && c1 - y1 * a.w <= pl.qr.cx1);
-    if (inside) return;
+  if (fill && !masked) return;
+  const int n0 = qt * kQT, n1 = min(n0 + kQT, pl.Mq);   // this tile's real queries
+  if (!fill && n1 <= n0) return;                        // the tile holds only the mean slot
+  int fc0 = 0;
+  if (fill) {   // cell tile: only rows outside the box's row range are written here
+    fc0 = ((int)blockIdx.x - nqt_max) * kQT;
+    const int y0 = fc0 / a.w, y1 = (min(fc0 + kQT, a.hw) - 1) / a.w;
+    if (pl.Mq > 0 && y0 >= pl.qr.cy0 && y1 <= pl.qr.cy1) return;
+  }
+  const int d0 = blockIdx.y * kCombCh;
+  const size_t sstride = (size_t)pl.nqt * kDo * kQT;   // between the splits of one query tile
+  auto ex = [&](float x) { return log2d ? exp2f(x) : expf(x); };
+
+  // First batch of this tile's partial fragments: requested NOW, before the weights are known, so
+  // that their latency overlaps the (m, l) loads and the three barriers of the weight phase.
+  // Thread = (query tile it = sl, lane qi) of the block's channel tiles; splits past the last one
+  // are clamped (re-read) and get weight 0.
+  constexpr int kU = 16 / kCombDt;       // splits per batch: 16 independent 16-byte loads in flight
+  constexpr int kE = kU < 4 ? kU : 4;    // splits of the early batch (small: duplicates cost bandwidth)
+  const float* __restrict__ psrc = wo + (size_t)(fill ? 0 : qt) * kDo * kQT + partial_frag_offset(d0 >> 4, sl, qi);
+  f32x4 v0[kE][kCombDt];
+#pragma unroll
+  for (int u = 0; u < kE; ++u)
+#pragma unroll
+    for (int k = 0; k < kCombDt; ++k) v0[u][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (!fill && pl.nsplit > 0) {   // (no split at all when every memory cell is masked: the read-out is 0)
+#pragma unroll
+    for (int u = 0; u < kE; ++u)
+#pragma unroll
+      for (int k = 0; k < kCombDt; ++k)
+        v0[u][k] = *reinterpret_cast<const f32x4*>(psrc + (size_t)min(u, pl.nsplit - 1) * sstride + (size_t)k * 1024);
+  }
+
+  // ---- mean-slot vector (one wave): weights of compacted query Mq, then its 64 channels
+  if (masked) {
+    const int qtm = pl.Mq >> 6, mq = pl.Mq & 63;
+    if (tid < RMNET_WAVE) {
+      const float* e = ml + ((size_t)(tid * pl.nqt + qtm) * 2) * kQT;
+      const bool on = tid < pl.nsplit;
+      const float ms = on ? e[mq] : -INFINITY;
+      float mtot = ms;
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) mtot = fmaxf(mtot, __shfl_xor(mtot, d));
+      if (n_out > 0.0f) mtot = fmaxf(mtot, 0.0f);
+      const float wgt = on ? ex(ms - mtot) : 0.0f;
+      float ltot = on ? e[kQT + mq] * wgt : 0.0f;
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) ltot += __shfl_xor(ltot, d);
+      if (n_out > 0.0f) ltot += n_out * ex(-mtot);
+      Wm[tid] = wgt / ltot;
+    }
+    __syncthreads();
+    {   // 256 threads = kCombCh channels x kTmParts interleaved subsets of the splits (loads independent)
+      constexpr int kTmParts = kThreads / kCombCh;
+      const int chn = tid % kCombCh, part = tid / kCombCh;
+      const float* __restrict__ src = wo + (size_t)qtm * kDo * kQT + partial_elem_offset(mq, d0 + chn);
+      float acc = 0.0f;
+#pragma unroll 4
+      for (int s = part; s < pl.nsplit; s += kTmParts) acc += Wm[s] * src[(size_t)s * sstride];
+      float* tp = &Tt[0][0];                         // (Tt is not in use yet)
+      tp[part * kCombCh + chn] = acc;
+      __syncthreads();
+      if (tid < kCombCh) {
+        float t = 0.0f;
+#pragma unroll
+        for (int p = 0; p < kTmParts; ++p) t += tp[p * kCombCh + tid];
+        Tm[tid] = t;
+      }
+    }
+    __syncthreads();
+  }
+
+  if (fill) {
+    const int cell = fc0 + qi;
+    if (cell >= a.hw) return;
+    const int cy = cell / a.w;
+    if (pl.Mq > 0 && cy >= pl.qr.cy0 && cy <= pl.qr.cy1) return;   // written by the query-tile blocks
+    float* __restrict__ out = a.out + (size_t)o * 2 * kDo * a.hw + cell;
+    const float* __restrict__ qv = a.qv + (size_t)o * kDo * a.hw + cell;
+#pragma unroll 8
+    for (int dd = sl; dd < kCombCh; dd += 4) {
+      const int d = d0 + dd;
+      out[(size_t)d * a.hw] = Tm[dd];
+      out[(size_t)(kDo + d) * a.hw] = qv[(size_t)d * a.hw] * 0.0f;   // q_val * box (:358), x*0 semantics
+    }
+    return;
   }
 
   // ---- split weights for the 64 queries of tile qt
   float mloc = -INFINITY;
+#pragma unroll 4
   for (int s = sl; s < pl.nsplit; s += 4) mloc = fmaxf(mloc, ml[((size_t)(s * pl.nqt + qt) * 2) * kQT + qi]);
   red[sl][qi] = mloc;
   __syncthreads();
@@ -402,89 +486,89 @@ __global__ __launch_bounds__(kThreads) void mr_combine(const KArgs a, int nqt_ma
   if (n_out > 0.0f) mtot = fmaxf(mtot, 0.0f);        // the N_out masked memory cells have S = 0
   __syncthreads();
   float lloc = 0.0f;
+#pragma unroll 4
   for (int s = sl; s < pl.nsplit; s += 4) {
     const float* e = ml + ((size_t)(s * pl.nqt + qt) * 2) * kQT;
-    const float wgt = log2d ? exp2f(e[qi] - mtot) : expf(e[qi] - mtot);
+    const float wgt = ex(e[qi] - mtot);
     Wt[s][qi] = wgt;
     lloc += e[kQT + qi] * wgt;
   }
   red[sl][qi] = lloc;
   __syncthreads();
   float ltot = red[0][qi] + red[1][qi] + red[2][qi] + red[3][qi];
-  if (n_out > 0.0f) ltot += n_out * (log2d ? exp2f(-mtot) : expf(-mtot));
+  if (n_out > 0.0f) ltot += n_out * ex(-mtot);
   const float inv = 1.0f / ltot;
   for (int s = sl; s < pl.nsplit; s += 4) Wt[s][qi] *= inv;
+  for (int s = pl.nsplit + sl; s < kE; s += 4) Wt[s][qi] = 0.0f;   // clamped duplicates of the early batch
   __syncthreads();
 
-  const int d0 = blockIdx.y * kCombCh;
-  const size_t sstride = (size_t)pl.nqt * kDo * kQT;   // between the splits of one query tile
-  if (!fill) {
-    {  // accumulate: thread = (query tile it = sl, lane qi) of the 4 channel tiles of this block
-      const int q = sl * 16 + (qi & 15), gg = qi >> 4;
-      f32x4 acc[kCombDt];
+  {  // accumulate: thread = (query tile it = sl, lane qi) of the channel tiles of this block
+    const int q = sl * 16 + (qi & 15), gg = qi >> 4;
+    f32x4 acc[kCombDt];
 #pragma unroll
-      for (int k = 0; k < kCombDt; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* __restrict__ src = wo + (size_t)qt * kDo * kQT + partial_frag_offset(d0 >> 4, sl, qi);
-      constexpr int kU = 16 / kCombDt;       // splits per batch: 16 independent 16-byte loads in flight
-      int s = 0;
-      for (; s + kU <= pl.nsplit; s += kU) {
-        f32x4 v[kU][kCombDt];
+    for (int k = 0; k < kCombDt; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* __restrict__ src = psrc;
 #pragma unroll
-        for (int u = 0; u < kU; ++u)
+    for (int u = 0; u < kE; ++u) {
+      const float wgt = Wt[u][q];
 #pragma unroll
-          for (int k = 0; k < kCombDt; ++k)
-            v[u][k] = *reinterpret_cast<const f32x4*>(src + (size_t)(s + u) * sstride + (size_t)k * 1024);
+      for (int k = 0; k < kCombDt; ++k) acc[k] += wgt * v0[u][k];
+    }
+    int s = kE;
+    for (; s + kU <= pl.nsplit; s += kU) {
+      f32x4 v[kU][kCombDt];
 #pragma unroll
-        for (int u = 0; u < kU; ++u) {
-          const float wgt = Wt[s + u][q];
-#pragma unroll
-          for (int k = 0; k < kCombDt; ++k) acc[k] += wgt * v[u][k];
-        }
-      }
-      for (; s < pl.nsplit; ++s) {
-        const float wgt = Wt[s][q];
+      for (int u = 0; u < kU; ++u)
 #pragma unroll
         for (int k = 0; k < kCombDt; ++k)
-          acc[k] += wgt * *reinterpret_cast<const f32x4*>(src + (size_t)s * sstride + (size_t)k * 1024);
+          v[u][k] = *reinterpret_cast<const f32x4*>(src + (size_t)(s + u) * sstride + (size_t)k * 1024);
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const float wgt = Wt[s + u][q];
+#pragma unroll
+        for (int k = 0; k < kCombDt; ++k) acc[k] += wgt * v[u][k];
       }
+    }
+    for (; s < pl.nsplit; ++s) {
+      const float wgt = Wt[s][q];
 #pragma unroll
       for (int k = 0; k < kCombDt; ++k)
+        acc[k] += wgt * *reinterpret_cast<const f32x4*>(src + (size_t)s * sstride + (size_t)k * 1024);
+    }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Tt[k * 16 + 4 * gg + r][q] = acc[k][r];
-    }
-    __syncthreads();
-    const int n = qt * kQT + qi;
-    if (n >= pl.Mq) return;                          // padding / mean slot: not a real cell
-    const int cell = REGIONAL ? query_cell(pl, a.w, n) : n;
-    float* __restrict__ out = a.out + (size_t)o * 2 * kDo * a.hw + cell;
-    const float* __restrict__ qv = a.qv + (size_t)o * kDo * a.hw + cell;
+    for (int k = 0; k < kCombDt; ++k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Tt[k * 16 + 4 * gg + r][q] = acc[k][r];
+  }
+  __syncthreads();
+
+  // ---- write-out: the contiguous cell range this tile owns
+  float* __restrict__ outo = a.out + (size_t)o * 2 * kDo * a.hw;
+  const float* __restrict__ qvo = a.qv + (size_t)o * kDo * a.hw;
+  if (!masked) {   // every cell is a query: tile qt = cells [n0, n1)
+    const int cell = n0 + qi;
+    if (cell >= n1) return;
 #pragma unroll 8
     for (int dd = sl; dd < kCombCh; dd += 4) {
       const int d = d0 + dd;
-      out[(size_t)d * a.hw] = Tt[dd][qi];
-      out[(size_t)(kDo + d) * a.hw] = qv[(size_t)d * a.hw];          // cat(mem, q_val), :163
+      outo[(size_t)d * a.hw + cell] = Tt[dd][qi];
+      outo[(size_t)(kDo + d) * a.hw + cell] = qvo[(size_t)d * a.hw + cell];     // cat(mem, q_val), :163
     }
-  } else {
-    // mean-slot vector for this block's channels -> LDS, then broadcast to the masked cells
-    const int mq = pl.Mq & 63;
-    if (tid < kCombCh) {
-      const float* __restrict__ src = wo + (size_t)qt * kDo * kQT + partial_elem_offset(mq, d0 + tid);
-      float acc = 0.0f;
-      for (int s = 0; s < pl.nsplit; ++s) acc += Wt[s][mq] * src[(size_t)s * sstride];
-      Tt[tid][0] = acc;
-    }
-    __syncthreads();
-    const int cell = ((int)blockIdx.x - nqt_max) * kQT + qi;
-    if (cell >= a.hw) return;
+    return;
+  }
+  const int rw = pl.qr.width();
+  const int c_begin = n0 == 0 ? pl.qr.cy0 * a.w : query_cell(pl, a.w, n0);
+  const int c_end = n1 == pl.Mq ? (pl.qr.cy1 + 1) * a.w : query_cell(pl, a.w, n1);   // exclusive
+  for (int cell = c_begin + qi; cell < c_end; cell += kQT) {
     const int cy = cell / a.w, cx = cell - cy * a.w;
-    if (pl.qr.contains(cy, cx)) return;              // written by the query-tile blocks
-    float* __restrict__ out = a.out + (size_t)o * 2 * kDo * a.hw + cell;
-    const float* __restrict__ qv = a.qv + (size_t)o * kDo * a.hw + cell;
+    const bool inside = cx >= pl.qr.cx0 && cx <= pl.qr.cx1;   // (the row is inside by construction)
+    const int q = inside ? (cy - pl.qr.cy0) * rw + (cx - pl.qr.cx0) - n0 : 0;
 #pragma unroll 8
     for (int dd = sl; dd < kCombCh; dd += 4) {
       const int d = d0 + dd;
-      out[(size_t)d * a.hw] = Tt[dd][0];
-      out[(size_t)(kDo + d) * a.hw] = qv[(size_t)d * a.hw] * 0.0f;   // q_val * box (:358), x*0 semantics
+      const float x = qvo[(size_t)d * a.hw + cell];
+      outo[(size_t)d * a.hw + cell] = inside ? Tt[dd][q] : Tm[dd];
+      outo[(size_t)(kDo + d) * a.hw + cell] = inside ? x : x * 0.0f;   // q_val * box (:358), x*0 semantics
     }
   }
 }
