@@ -113,6 +113,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-miopen-find', action='store_true',
                     help='leave torch.backends.cudnn.benchmark off (MIOpen immediate mode; ~5 %% slower convs)')
+    ap.add_argument('--no-fuse-epilogue', action='store_true',
+                    help='keep BatchNorm / bias / skip add / ReLU as separate torch kernels '
+                         '(default: one rmnet_channel_affine_f32 pass per convolution)')
     ap.add_argument('--fold-bn', action='store_true',
                     help='fold eval-mode BatchNorm into the trunk convolutions (measured: no gain at 4 clips/GPU)')
     ap.add_argument('--channels-last', action='store_true', help='conv stacks in NHWC memory format (experiment)')
@@ -143,6 +146,8 @@ def main():
     tfn = networks.procedural_init_(TinyFlowNet(None)).to(dev).eval()
     if args.fold_bn:
         net.fuse_for_inference()
+    elif not args.no_fuse_epilogue and not args.channels_last:
+        net.fuse_epilogues()
     if args.channels_last:
         net = net.to(memory_format=torch.channels_last)
         tfn = tfn.to(memory_format=torch.channels_last)
@@ -264,7 +269,8 @@ def main():
                        'sharding': 'one clip per rank',
                        'miopen_find': not args.no_miopen_find, 'channels_last': bool(args.channels_last),
                        'hip_graph': bool(args.graph), 'clips_per_gpu': B,
-                       'batchnorm_folded': bool(args.fold_bn)},
+                       'batchnorm_folded': bool(args.fold_bn),
+                       'fused_epilogues': bool(not args.fold_bn and not args.no_fuse_epilogue and not args.channels_last)},
             'roofline': {'bound': 'hbm', 'kernel': 'bk_main (fused regional memory read, split-fp16 MFMA bank kernel)',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,

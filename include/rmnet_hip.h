@@ -144,6 +144,18 @@ int rmnet_bank_read_f32(const void *bank, int no, int Tcap, int h, int w, int T,
 int rmnet_rect_mask_f32(const float *x, int n, int C, int T, int h, int w, const int32_t *rects,
                         float *y, void *stream);
 
+/* C1 glue: per-channel affine + residual + ReLU in one pass over an NCHW fp32 activation,
+ *   out[n,c,:] = act(x[n,c,:] * scale[c] + shift[c] + (res[n,c,:] * res_scale[c] + res_shift[c]))
+ * scale / shift / res / res_scale / res_shift may each be NULL (1, 0, no residual, 1, 0); relu != 0
+ * clamps at 0 (NaN propagates like torch.relu).  In place (out == x or out == res) is allowed.
+ * Replaces the elementwise passes the reference runs after every convolution in eval mode:
+ * BatchNorm2d + ReLU + skip add of the torchvision Bottleneck (models/rmnet.py:66-80, 96-103 use
+ * resnet50's layers) and conv bias + ReLU + skip add of ResBlock (models/rmnet.py:24-48), with
+ * scale/shift = gamma/sqrt(var+eps), beta - mean*scale  or  (NULL, conv bias). */
+int rmnet_channel_affine_f32(const float *x, const float *scale, const float *shift,
+                             const float *res, const float *res_scale, const float *res_shift,
+                             int relu, long long N, int C, long long HW, float *out, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * F1  Optical-flow update after two affine warps.
  * Replaces: CPython `flow_affine_transformation.update_optical_flow(flow, M1, M2)` --

@@ -8,7 +8,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['capi.hip', 'region_map.hip', 'flow_affine.hip', 'memory_read.hip', 'bank.hip']
+SOURCES = ['capi.hip', 'region_map.hip', 'flow_affine.hip', 'memory_read.hip', 'bank.hip', 'epilogue.hip']
 LIB = os.path.join(HERE, 'librmnet_hip.so')
 ARCH = 'gfx950'
 

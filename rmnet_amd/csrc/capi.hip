@@ -112,6 +112,13 @@ int rmnet_rect_mask_f32(const float* x, int n, int C, int T, int h, int w, const
   return launch_rect_mask(x, n, C, T, h, w, rects, y, static_cast<hipStream_t>(stream));
 }
 
+int rmnet_channel_affine_f32(const float* x, const float* scale, const float* shift, const float* res,
+                             const float* res_scale, const float* res_shift, int relu, long long N,
+                             int C, long long HW, float* out, void* stream) {
+  return launch_channel_affine(x, scale, shift, res, res_scale, res_shift, relu, N, C, HW, out,
+                               static_cast<hipStream_t>(stream));
+}
+
 int rmnet_flow_affine_f32(const float* flow, const float* m1, const float* m2, int H, int W,
                           float* out, void* stream) {
   return launch_flow_affine(flow, m1, m2, H, W, out, static_cast<hipStream_t>(stream));

@@ -63,6 +63,9 @@ int launch_boxes_to_rects(const int32_t* bboxes, int n, int k_per_batch, int pad
                           int stride, int ch, int cw, int32_t* rects, hipStream_t st);
 int launch_rect_mask(const float* x, int n, int C, int T, int h, int w, const int32_t* rects,
                      float* y, hipStream_t st);
+int launch_channel_affine(const float* x, const float* scale, const float* shift, const float* res,
+                          const float* rscale, const float* rshift, int relu, long long N, int C,
+                          long long HW, float* out, hipStream_t st);
 int launch_flow_affine(const float* flow, const float* m1, const float* m2, int H, int W,
                        float* out, hipStream_t st);
 

@@ -44,11 +44,28 @@ class _Bottleneck(nn.Module):
                                             nn.BatchNorm2d(c_out))
 
     def forward(self, x):
+        if getattr(self, '_fused', False) and x.is_cuda:
+            return self._forward_fused(x)
         skip = x if self.downsample is None else self.downsample(x)
         y = self.relu(self.bn1(self.conv1(x)))
         y = self.relu(self.bn2(self.conv2(y)))
         y = self.bn3(self.conv3(y))
         return self.relu(y + skip)
+
+    def _forward_fused(self, x):
+        """Same block with BatchNorm(eval) / skip add / ReLU fused into one pass per convolution
+        (rmnet_channel_affine_f32): 3 elementwise kernels instead of 7-8."""
+        from . import ops
+        t = self.conv1(x)
+        ops.channel_affine(t, self._s1, self._b1, relu=True, out=t)
+        t = self.conv2(t)
+        ops.channel_affine(t, self._s2, self._b2, relu=True, out=t)
+        t = self.conv3(t)
+        if self.downsample is None:
+            return ops.channel_affine(t, self._s3, self._b3, res=x, relu=True, out=t)
+        d = self.downsample[0](x)
+        return ops.channel_affine(t, self._s3, self._b3, res=d, res_scale=self._sd, res_shift=self._bd,
+                                  relu=True, out=t)
 
 
 def _stage(c_in, width, n_blocks, stride):
@@ -89,8 +106,25 @@ class ResBlock(nn.Module):
         self.conv2 = nn.Conv2d(outdim, outdim, 3, padding=1)
 
     def forward(self, x):
+        if getattr(self, '_fused', False) and x.is_cuda:
+            return self._forward_fused(x)
         r = self.conv2(F.relu(self.conv1(F.relu(x))))
         return (x if self.downsample is None else self.downsample(x)) + r
+
+    def _forward_fused(self, x):
+        """Same arithmetic: the convolutions run without bias and one pass adds the bias with the
+        ReLU (conv1) or with the skip (conv2) -- 3 elementwise kernels instead of 5.  (Not always
+        bit-identical: MIOpen may choose another solver for the bias-free convolution.)"""
+        from . import ops
+        c1, c2 = self.conv1, self.conv2
+        t = F.conv2d(F.relu(x), c1.weight, None, c1.stride, c1.padding)
+        ops.channel_affine(t, None, c1.bias, relu=True, out=t)
+        r = F.conv2d(t, c2.weight, None, c2.stride, c2.padding)
+        if self.downsample is None:
+            return ops.channel_affine(r, None, c2.bias, res=x, out=r)
+        ds = self.downsample
+        d = F.conv2d(x, ds.weight, None, ds.stride, ds.padding)
+        return ops.channel_affine(r, None, c2.bias, res=d, res_shift=ds.bias, out=r)
 
 
 class EncoderMemory(nn.Module):
@@ -107,7 +141,12 @@ class EncoderMemory(nn.Module):
     def forward(self, in_f, in_m, in_o):
         m = in_m.unsqueeze(1).float()
         o = in_o.unsqueeze(1).float()
-        c1 = self.relu(self.bn1(self.conv1(in_f) + self.conv1_m(m) + self.conv1_o(o)))
+        if getattr(self, '_fused', False) and in_f.is_cuda:
+            from . import ops
+            t = self.conv1(in_f).add_(self.conv1_m(m)).add_(self.conv1_o(o))
+            c1 = ops.channel_affine(t, self._s1, self._b1, relu=True, out=t)
+        else:
+            c1 = self.relu(self.bn1(self.conv1(in_f) + self.conv1_m(m) + self.conv1_o(o)))
         r2 = self.res2(self.maxpool(c1))
         r3 = self.res3(r2)
         r4 = self.res4(r3)
@@ -124,7 +163,12 @@ class EncoderQuery(nn.Module):
         self.res2, self.res3, self.res4 = trunk.layer1, trunk.layer2, trunk.layer3
 
     def forward(self, in_f):
-        c1 = self.relu(self.bn1(self.conv1(in_f)))
+        if getattr(self, '_fused', False) and in_f.is_cuda:
+            from . import ops
+            t = self.conv1(in_f)
+            c1 = ops.channel_affine(t, self._s1, self._b1, relu=True, out=t)
+        else:
+            c1 = self.relu(self.bn1(self.conv1(in_f)))
         r2 = self.res2(self.maxpool(c1))
         r3 = self.res3(r2)
         r4 = self.res4(r3)
@@ -281,4 +325,42 @@ def fold_batchnorm_(module):
             m.conv1_m.weight.mul_(scale.view(-1, 1, 1, 1))
             m.conv1_o.weight.mul_(scale.view(-1, 1, 1, 1))
             m.conv1, m.bn1 = fused, _Identity()
+    return module
+
+
+# ----------------------------------------------------------------------------------------------
+# Fused elementwise epilogues (eval mode, GPU only).  Unlike fold_batchnorm_ this keeps every
+# parameter and the state dict untouched: the BatchNorm statistics are only re-expressed as a
+# per-channel (scale, shift) pair held in non-persistent buffers, and the forward passes of
+# _Bottleneck / ResBlock / the encoder stems call rmnet_channel_affine_f32 once per convolution
+# instead of BatchNorm -> add -> ReLU (or bias -> ReLU / bias -> add) as separate kernels.
+# ----------------------------------------------------------------------------------------------
+@torch.no_grad()
+def fuse_epilogues_(module, enable=True):
+    """Switch ``module`` (an ``RMNet`` or any sub-module) to the fused elementwise path; call after
+    loading weights, in eval mode.  ``enable=False`` switches back."""
+    def put(m, name, t):
+        if name in m._buffers:
+            m._buffers[name] = t
+        else:
+            m.register_buffer(name, t, persistent=False)
+
+    for m in module.modules():
+        if isinstance(m, _Bottleneck):
+            for i, bn in ((1, m.bn1), (2, m.bn2), (3, m.bn3)):
+                sc, sh = _bn_scale_shift(bn)
+                put(m, '_s%d' % i, sc.contiguous())
+                put(m, '_b%d' % i, sh.contiguous())
+            if m.downsample is not None:
+                sc, sh = _bn_scale_shift(m.downsample[1])
+                put(m, '_sd', sc.contiguous())
+                put(m, '_bd', sh.contiguous())
+            m._fused = bool(enable)
+        elif isinstance(m, (EncoderMemory, EncoderQuery)):
+            sc, sh = _bn_scale_shift(m.bn1)
+            put(m, '_s1', sc.contiguous())
+            put(m, '_b1', sh.contiguous())
+            m._fused = bool(enable)
+        elif isinstance(m, ResBlock):
+            m._fused = bool(enable)
     return module

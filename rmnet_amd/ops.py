@@ -216,6 +216,41 @@ def rect_mask(x, rects):
     return y
 
 
+def channel_affine(x, scale=None, shift=None, res=None, res_scale=None, res_shift=None, relu=False,
+                   out=None):
+    """out = act(x * scale[c] + shift[c] + (res * res_scale[c] + res_shift[c])) for NCHW fp32 ``x`` in
+    one pass (csrc/epilogue.hip).  ``out`` may be ``x`` or ``res`` (in place); default: a new tensor.
+    Replaces BatchNorm2d(eval) / conv bias / skip add / ReLU sequences around the convolutions."""
+    _check(x, 'x')
+    if x.dim() != 4:
+        raise RuntimeError('x must be [N,C,H,W]')
+    N, C, H, W = x.shape
+    for t, n in ((scale, 'scale'), (shift, 'shift'), (res_scale, 'res_scale'), (res_shift, 'res_shift')):
+        if t is not None:
+            _check(t, n)
+            if t.numel() != C:
+                raise RuntimeError('%s must have C = %d elements' % (n, C))
+    if res is not None:
+        _check(res, 'res')
+        if res.shape != x.shape:
+            raise RuntimeError('res must have the shape of x')
+    elif res_scale is not None or res_shift is not None:
+        raise RuntimeError('res_scale / res_shift without res')
+    if out is None:
+        out = torch.empty_like(x)
+    else:
+        _check(out, 'out')
+        if out.shape != x.shape:
+            raise RuntimeError('out must have the shape of x')
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        rc = lib.rmnet_channel_affine_f32(_ptr(x), _ptr(scale), _ptr(shift), _ptr(res), _ptr(res_scale),
+                                          _ptr(res_shift), 1 if relu else 0, N, C, H * W, _ptr(out),
+                                          _stream(x.device))
+    _lib.check(rc, 'rmnet_channel_affine_f32')
+    return out
+
+
 def flow_affine(flow, m1, m2):
     """Device-resident variant: flow [H,W,2] f32 cuda, m1/m2 [2,3] f32 cuda -> [H,W,2]."""
     for t, n in ((flow, 'flow'), (m1, 'm1'), (m2, 'm2')):

@@ -85,6 +85,16 @@ class RMNet(nn.Module):
         fold_batchnorm_(self.encoder_query)
         return self
 
+    def fuse_epilogues(self, enable=True):
+        """Run BatchNorm(eval) / conv bias / skip add / ReLU as ONE pass per convolution
+        (rmnet_channel_affine_f32) in both encoders and the decoder.  Parameters and state dict are
+        untouched; results differ from the module graph by fp32 rounding only (tests: 1e-5 relative per
+        block, mask probabilities < 1e-3 per clip)."""
+        from .networks import fuse_epilogues_
+        self.eval()
+        fuse_epilogues_(self, enable)
+        return self
+
     # ------------------------------------------------------------------ small helpers
     @staticmethod
     def _object_index(n_objects, K, device):

@@ -534,3 +534,78 @@ def test_batchnorm_folding_keeps_the_masks(golden_dir, oracle_mod):
         b = fused(frames, masks, flows, n_objects, 1)
     assert float((a - b).abs().max()) < 1e-3
     assert (a.argmax(2) == b.argmax(2)).float().mean() > 0.999
+
+
+@pytest.mark.parametrize('N,C,H,W', [(2, 5, 7, 9), (1, 64, 240, 432), (3, 16, 30, 54), (1, 3, 1, 1)])
+def test_channel_affine_is_the_torch_expression(N, C, H, W):
+    """rmnet_channel_affine_f32 == act(x*scale + shift + (res*rscale + rshift)) evaluated by torch op
+    by op (bit-exact: the kernel is compiled without FMA contraction), every optional operand,
+    in place, and the unaligned scalar path."""
+    from rmnet_amd import ops
+    g = torch.Generator().manual_seed(N * 100 + C)
+    x = torch.randn(N, C, H, W, generator=g).to(dev())
+    r = torch.randn(N, C, H, W, generator=g).to(dev())
+    sc, sh, rs, rh = [torch.randn(C, generator=g).to(dev()) for _ in range(4)]
+    v = lambda t: t.view(1, C, 1, 1)
+    assert torch.equal(ops.channel_affine(x, sc, sh), x * v(sc) + v(sh))
+    assert torch.equal(ops.channel_affine(x, sc, sh, relu=True), torch.relu(x * v(sc) + v(sh)))
+    assert torch.equal(ops.channel_affine(x, None, sh, res=r), (x + v(sh)) + r)
+    assert torch.equal(ops.channel_affine(x, sc, sh, res=r, res_scale=rs, res_shift=rh, relu=True),
+                       torch.relu((x * v(sc) + v(sh)) + (r * v(rs) + v(rh))))
+    y = x.clone()
+    assert ops.channel_affine(y, sc, None, res=r, res_shift=rh, out=y) is y      # in place on x
+    assert torch.equal(y, x * v(sc) + (r + v(rh)))
+    y = r.clone()
+    ops.channel_affine(x, None, None, res=y, relu=True, out=y)                 # in place on the residual
+    assert torch.equal(y, torch.relu(x + r))
+    if H * W > 4:                                                              # 4-byte aligned views only
+        xs, rs_ = x.flatten()[1:1 + (N * C * H * W - C * H * W)], r.flatten()[1:1 + (N * C * H * W - C * H * W)]
+        if N > 1:
+            xs, rs_ = xs.view(N - 1, C, H, W), rs_.view(N - 1, C, H, W)
+            assert torch.equal(ops.channel_affine(xs, sc, sh, res=rs_, relu=True), torch.relu((xs * v(sc) + v(sh)) + rs_))
+    x[0, 0, 0, 0] = float('nan')
+    assert torch.isnan(ops.channel_affine(x, sc, sh, relu=True)[0, 0, 0, 0])    # torch.relu keeps NaN
+    with pytest.raises(RuntimeError):
+        ops.channel_affine(x.cpu(), sc, sh)
+    with pytest.raises(RuntimeError):
+        ops.channel_affine(x, sc[:-1].contiguous(), sh)
+
+
+def test_fused_epilogues_match_the_module_graph(oracle_mod):
+    """fuse_epilogues(): ResBlocks and Bottleneck trunks within fp32 rounding of the module graph
+    (BatchNorm re-expressed as scale/shift, bias added after the convolution), parameters and state
+    dict untouched, whole clip within the mask bar."""
+    import copy
+    from rmnet_amd import networks
+    from rmnet_amd.synthetic import synthetic_clip
+    prod, _ = _nets(oracle_mod)
+    for m in prod.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.uniform_(-0.1, 0.1)
+            m.running_var.uniform_(0.8, 1.25)
+            m.weight.data.uniform_(0.8, 1.2)
+            m.bias.data.uniform_(-0.1, 0.1)
+    fused = copy.deepcopy(prod).fuse_epilogues()
+    assert list(fused.state_dict().keys()) == list(prod.state_dict().keys())
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for blk_p, blk_f in zip(prod.modules(), fused.modules()):
+            if isinstance(blk_p, networks.ResBlock):
+                cin = blk_p.conv1.in_channels
+                x = torch.randn(2, cin, 12, 20, generator=g).to(dev())
+                a, b = blk_p(x), blk_f(x)       # (MIOpen may pick another solver without the bias)
+                assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+        x = torch.randn(2, 3, 64, 96, generator=g).to(dev())
+        for a, b in zip(prod.encoder_query(x)[:3], fused.encoder_query(x)[:3]):
+            assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
+        m = (torch.rand(2, 64, 96, generator=g) > 0.5).float().to(dev())
+        for a, b in zip(prod.encoder_memory(x, m, 1 - m)[:3], fused.encoder_memory(x, m, 1 - m)[:3]):
+            assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
+        frames, masks, flows, n_objects = synthetic_clip(3, 3, 96, 160, seed=11, size=1.3)
+        a = prod(frames, masks, flows, n_objects, 1)
+        b = fused(frames, masks, flows, n_objects, 1)
+    assert float((a - b).abs().max()) < 1e-3
+    assert (a.argmax(2) == b.argmax(2)).float().mean() > 0.999
+    fused.fuse_epilogues(False)
+    with torch.no_grad():   # switched back: the plain module graph again (up to MIOpen's own run-to-run choices)
+        assert float((fused(frames, masks, flows, n_objects, 1) - a).abs().max()) < 1e-3
