@@ -156,6 +156,13 @@ int rmnet_channel_affine_f32(const float *x, const float *scale, const float *sh
                              const float *res, const float *res_scale, const float *res_shift,
                              int relu, long long N, int C, long long HW, float *out, void *stream);
 
+/* C1 glue: out = skip + bilinear_x2(x), x [N,C,h,w] -> out / skip [N,C,2h,2w] fp32 NCHW, with
+ * torch's align_corners=False source-index rule.  skip may be NULL (plain upsample); out may be skip.
+ * Replaces F.interpolate(pm, scale_factor=2, mode='bilinear') and the add of Refine.forward
+ * (models/rmnet.py:117-119). */
+int rmnet_upsample2x_add_f32(const float *x, const float *skip, long long N, int C, int h, int w,
+                             float *out, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * F1  Optical-flow update after two affine warps.
  * Replaces: CPython `flow_affine_transformation.update_optical_flow(flow, M1, M2)` --

@@ -52,6 +52,8 @@ SIGNATURES = {
     'rmnet_channel_affine_f32': (ctypes.c_int, [
         c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_longlong, ctypes.c_int,
         ctypes.c_longlong, c_f32p, ctypes.c_void_p]),
+    'rmnet_upsample2x_add_f32': (ctypes.c_int, [
+        c_f32p, c_f32p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_void_p]),
     'rmnet_flow_affine_f32': (ctypes.c_int, [
         c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_void_p]),
     'rmnet_flow_affine_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),

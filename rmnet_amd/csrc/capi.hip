@@ -119,6 +119,11 @@ int rmnet_channel_affine_f32(const float* x, const float* scale, const float* sh
                                static_cast<hipStream_t>(stream));
 }
 
+int rmnet_upsample2x_add_f32(const float* x, const float* skip, long long N, int C, int h, int w,
+                             float* out, void* stream) {
+  return launch_upsample2x_add(x, skip, N, C, h, w, out, static_cast<hipStream_t>(stream));
+}
+
 int rmnet_flow_affine_f32(const float* flow, const float* m1, const float* m2, int H, int W,
                           float* out, void* stream) {
   return launch_flow_affine(flow, m1, m2, H, W, out, static_cast<hipStream_t>(stream));

@@ -66,6 +66,8 @@ int launch_rect_mask(const float* x, int n, int C, int T, int h, int w, const in
 int launch_channel_affine(const float* x, const float* scale, const float* shift, const float* res,
                           const float* rscale, const float* rshift, int relu, long long N, int C,
                           long long HW, float* out, hipStream_t st);
+int launch_upsample2x_add(const float* x, const float* skip, long long N, int C, int h, int w,
+                          float* out, hipStream_t st);
 int launch_flow_affine(const float* flow, const float* m1, const float* m2, int H, int W,
                        float* out, hipStream_t st);
 

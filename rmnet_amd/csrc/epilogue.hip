@@ -73,6 +73,68 @@ __global__ __launch_bounds__(kThreads) void channel_affine(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// x2 bilinear upsample (align_corners = False) fused with the skip add of Refine
+// (models/rmnet.py:117-119: s + F.interpolate(pm, scale_factor=2, mode='bilinear')).
+// torch's generic upsample kernel spends ~480 us on the [4,256,60,108] -> [4,256,120,216] map of the
+// 480p decoder (0.2 TB/s) and the add is one more pass; here one thread produces 4 consecutive
+// outputs of a row from 2 x 4 source values (weights are exactly 0.25 / 0.75, or 0 / 1 at the
+// border clamp of area_pixel_compute_source_index), adds the skip and stores 16 bytes.
+//   src = 0.5 * (dst + 0.5) - 0.5, clamped at 0;  i0 = floor(src);  i1 = i0 + (i0 < n - 1);
+//   l1 = src - i0;  l0 = 1 - l1;  out = l0y * (l0x * v00 + l1x * v01) + l1y * (l0x * v10 + l1x * v11)
+// (aten/src/ATen/native/cuda/UpSampleBilinear2d.cu: upsample_bilinear2d_out_frame).
+struct Tap { int i0, i1; float l0, l1; };
+__device__ inline Tap tap2x(int d, int n) {
+  float src = 0.5f * ((float)d + 0.5f) - 0.5f;
+  src = src < 0.0f ? 0.0f : src;
+  Tap t;
+  t.i0 = (int)src;
+  t.i1 = t.i0 + (t.i0 < n - 1 ? 1 : 0);
+  t.l1 = src - (float)t.i0;
+  t.l0 = 1.0f - t.l1;
+  return t;
+}
+
+template <bool VEC4, bool ADD>
+__global__ __launch_bounds__(kThreads) void upsample2x_add(const float* __restrict__ x,
+                                                           const float* skip, float* out, int h,
+                                                           int w, long long planes) {
+  const int H = 2 * h, W = 2 * w;
+  const int per_row = VEC4 ? W >> 2 : W;
+  const long long items = (long long)H * per_row;
+  for (long long plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+    const float* xp = x + (size_t)plane * h * w;
+    const size_t ob = (size_t)plane * H * W;
+    for (long long it = (long long)blockIdx.x * kThreads + threadIdx.x; it < items;
+         it += (long long)gridDim.x * kThreads) {
+      const int y = (int)(it / per_row), xq = (int)(it - (long long)y * per_row);
+      const Tap ty = tap2x(y, h);
+      const float* r0 = xp + (size_t)ty.i0 * w;
+      const float* r1 = xp + (size_t)ty.i1 * w;
+      if (VEC4) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const Tap tx = tap2x(4 * xq + e, w);
+          o[e] = ty.l0 * (tx.l0 * r0[tx.i0] + tx.l1 * r0[tx.i1]) + ty.l1 * (tx.l0 * r1[tx.i0] + tx.l1 * r1[tx.i1]);
+        }
+        const size_t oi = ob + (size_t)y * W + 4 * xq;
+        if (ADD) {
+          const float4 s = *reinterpret_cast<const float4*>(skip + oi);
+          o[0] = s.x + o[0]; o[1] = s.y + o[1]; o[2] = s.z + o[2]; o[3] = s.w + o[3];
+        }
+        *reinterpret_cast<float4*>(out + oi) = float4{o[0], o[1], o[2], o[3]};
+      } else {
+        const Tap tx = tap2x(xq, w);
+        float o = ty.l0 * (tx.l0 * r0[tx.i0] + tx.l1 * r0[tx.i1]) + ty.l1 * (tx.l0 * r1[tx.i0] + tx.l1 * r1[tx.i1]);
+        const size_t oi = ob + (size_t)y * W + xq;
+        if (ADD) o = skip[oi] + o;
+        out[oi] = o;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 int launch_channel_affine(const float* x, const float* scale, const float* shift, const float* res,
@@ -93,6 +155,26 @@ int launch_channel_affine(const float* x, const float* scale, const float* shift
   if (vec) { if (res) RMNET_CA(true, true); else RMNET_CA(true, false); }
   else     { if (res) RMNET_CA(false, true); else RMNET_CA(false, false); }
 #undef RMNET_CA
+  return check_launch();
+}
+
+}  // namespace rmnet
+
+namespace rmnet {
+
+int launch_upsample2x_add(const float* x, const float* skip, long long N, int C, int h, int w,
+                          float* out, hipStream_t st) {
+  if (!x || !out || N <= 0 || C <= 0 || h <= 0 || w <= 0) return RMNET_E_INVALID_ARG;
+  const long long planes = N * C;
+  const bool vec = (w & 1) == 0 && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(skip)) & 15) == 0;
+  const long long items = (long long)2 * h * (vec ? (2 * w) >> 2 : 2 * w);
+  long long chunks = (items + kThreads - 1) / kThreads;
+  if (chunks > 256) chunks = 256;
+  const dim3 grid((unsigned)chunks, (unsigned)(planes < 65535 ? planes : 65535));
+#define RMNET_UP(V, A) hipLaunchKernelGGL((upsample2x_add<V, A>), grid, dim3(kThreads), 0, st, x, skip, out, h, w, planes)
+  if (vec) { if (skip) RMNET_UP(true, true); else RMNET_UP(true, false); }
+  else     { if (skip) RMNET_UP(false, true); else RMNET_UP(false, false); }
+#undef RMNET_UP
   return check_launch();
 }
 

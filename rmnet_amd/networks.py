@@ -187,6 +187,9 @@ class Refine(nn.Module):
 
     def forward(self, f, pm):
         s = self.ResFS(self.convFS(f))
+        if getattr(self, '_fused', False) and s.is_cuda and self.scale_factor == 2:
+            from . import ops
+            return self.ResMM(ops.upsample2x_add(pm, s, out=s))     # s + up in one pass
         up = F.interpolate(pm, scale_factor=self.scale_factor, mode='bilinear', align_corners=False)
         return self.ResMM(s + up)
 
@@ -361,6 +364,6 @@ def fuse_epilogues_(module, enable=True):
             put(m, '_s1', sc.contiguous())
             put(m, '_b1', sh.contiguous())
             m._fused = bool(enable)
-        elif isinstance(m, ResBlock):
+        elif isinstance(m, (ResBlock, Refine)):
             m._fused = bool(enable)
     return module

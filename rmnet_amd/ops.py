@@ -251,6 +251,31 @@ def channel_affine(x, scale=None, shift=None, res=None, res_scale=None, res_shif
     return out
 
 
+def upsample2x_add(x, skip=None, out=None):
+    """skip + F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False) in one pass
+    (csrc/epilogue.hip); ``skip`` None = plain upsample; ``out`` may be ``skip`` (in place)."""
+    _check(x, 'x')
+    if x.dim() != 4:
+        raise RuntimeError('x must be [N,C,h,w]')
+    N, C, h, w = x.shape
+    shape = (N, C, 2 * h, 2 * w)
+    if skip is not None:
+        _check(skip, 'skip')
+        if tuple(skip.shape) != shape:
+            raise RuntimeError('skip must be [N,C,2h,2w]')
+    if out is None:
+        out = torch.empty(shape, dtype=x.dtype, device=x.device)
+    else:
+        _check(out, 'out')
+        if tuple(out.shape) != shape:
+            raise RuntimeError('out must be [N,C,2h,2w]')
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        rc = lib.rmnet_upsample2x_add_f32(_ptr(x), _ptr(skip), N, C, h, w, _ptr(out), _stream(x.device))
+    _lib.check(rc, 'rmnet_upsample2x_add_f32')
+    return out
+
+
 def flow_affine(flow, m1, m2):
     """Device-resident variant: flow [H,W,2] f32 cuda, m1/m2 [2,3] f32 cuda -> [H,W,2]."""
     for t, n in ((flow, 'flow'), (m1, 'm1'), (m2, 'm2')):

@@ -609,3 +609,25 @@ def test_fused_epilogues_match_the_module_graph(oracle_mod):
     fused.fuse_epilogues(False)
     with torch.no_grad():   # switched back: the plain module graph again (up to MIOpen's own run-to-run choices)
         assert float((fused(frames, masks, flows, n_objects, 1) - a).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize('N,C,h,w', [(2, 3, 5, 6), (1, 8, 30, 54), (1, 2, 7, 9), (1, 1, 1, 1), (4, 16, 60, 108)])
+def test_upsample2x_add_is_torch_bilinear(N, C, h, w):
+    """rmnet_upsample2x_add_f32 == skip + F.interpolate(x, scale_factor=2, 'bilinear',
+    align_corners=False): same source-index rule and the same expression; the weights are exactly
+    0, 0.25, 0.75 or 1, so only FMA contraction inside torch's own kernel can differ (<= 1 ulp of the
+    largest term)."""
+    import torch.nn.functional as F
+    from rmnet_amd import ops
+    g = torch.Generator().manual_seed(h * 100 + w)
+    x = torch.randn(N, C, h, w, generator=g).to(dev())
+    s = torch.randn(N, C, 2 * h, 2 * w, generator=g).to(dev())
+    up = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
+    got = ops.upsample2x_add(x)
+    assert float((got - up).abs().max()) <= 4e-7 * max(1.0, float(x.abs().max()))
+    got = ops.upsample2x_add(x, s)
+    assert float((got - (s + up)).abs().max()) <= 6e-7 * max(1.0, float(x.abs().max()) + float(s.abs().max()))
+    t = s.clone()
+    assert ops.upsample2x_add(x, t, out=t) is t and torch.equal(t, got)        # in place on the skip
+    with pytest.raises(RuntimeError):
+        ops.upsample2x_add(x, s[:, :, :-1].contiguous())
