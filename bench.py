@@ -172,8 +172,10 @@ def main():
     def frame_body(prev_frame, prev_mask, cur_frame):
         # one frame of the loop; all of the step's work, incl. the final soft-max, is done
         flow = tfn._forward(cur_frame, prev_frame)
-        logit = net.frame_step(ctx, bank, prev_frame, prev_mask, cur_frame, flow, commit=False)
-        return torch.softmax(logit, dim=1)
+        out = net.frame_step(ctx, bank, prev_frame, prev_mask, cur_frame, flow, commit=False)
+        if isinstance(out, tuple):          # fused decoder tail: (logits, soft-max of the logits)
+            return out[1]
+        return torch.softmax(out, dim=1)
 
     def eager_step(i, ev=None):
         # frames cycle through the clip; the mask fed back is the synthetic blob of frame t-1 (with

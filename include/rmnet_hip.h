@@ -163,6 +163,16 @@ int rmnet_channel_affine_f32(const float *x, const float *scale, const float *sh
 int rmnet_upsample2x_add_f32(const float *x, const float *skip, long long N, int C, int h, int w,
                              float *out, void *stream);
 
+/* P3/P4 tail: decoder logits -> foreground probability -> soft aggregation -> un-pad (-> soft-max over
+ * the K mask channels) in one pass.  dec [n_tot,2,Hp,Wp]: 2-class logits of the objects in flight;
+ * clip b owns objects [obj_begin[b], obj_begin[b+1]) (device int32 [B+1]); logit / prob [B,K,H,W] with
+ * H,W the un-padded size and (pad_l, pad_t) the padding removed on the left / top.  prob may be NULL.
+ * Replaces F.softmax(logit, dim=1)[:, 1], RMNet.soft_aggregation, the un-pad slicing and the per-frame
+ * F.softmax of the frame loop: models/rmnet.py:368-380, 289-302, 450. */
+int rmnet_soft_aggregate_f32(const float *dec, const int32_t *obj_begin, int B, int K, int Hp, int Wp,
+                             int pad_l, int pad_t, int H, int W, float *logit, float *prob,
+                             void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * F1  Optical-flow update after two affine warps.
  * Replaces: CPython `flow_affine_transformation.update_optical_flow(flow, M1, M2)` --

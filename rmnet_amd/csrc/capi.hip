@@ -124,6 +124,13 @@ int rmnet_upsample2x_add_f32(const float* x, const float* skip, long long N, int
   return launch_upsample2x_add(x, skip, N, C, h, w, out, static_cast<hipStream_t>(stream));
 }
 
+int rmnet_soft_aggregate_f32(const float* dec, const int32_t* obj_begin, int B, int K, int Hp, int Wp,
+                             int pad_l, int pad_t, int H, int W, float* logit, float* prob,
+                             void* stream) {
+  return launch_soft_aggregate(dec, obj_begin, B, K, Hp, Wp, pad_l, pad_t, H, W, logit, prob,
+                               static_cast<hipStream_t>(stream));
+}
+
 int rmnet_flow_affine_f32(const float* flow, const float* m1, const float* m2, int H, int W,
                           float* out, void* stream) {
   return launch_flow_affine(flow, m1, m2, H, W, out, static_cast<hipStream_t>(stream));

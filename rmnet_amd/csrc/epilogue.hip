@@ -135,6 +135,66 @@ __global__ __launch_bounds__(kThreads) void upsample2x_add(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Decoder tail: 2-class soft-max -> foreground probability -> soft aggregation
+// (models/rmnet.py:289-302: background = prod(1 - p_o), clamp to [1e-7, 1 - 1e-7], logit =
+// log(em / (1 - em))) -> un-pad (:375-380) -> optional soft-max over the K channels (:450) in ONE pass.
+// The module graph spends ~25 small launches per frame on [B,K,H,W]-sized tensors for this.
+//   dec [n_tot, 2, Hp, Wp] decoder logits of the objects in flight, clip b owning objects
+//   [obj_begin[b], obj_begin[b+1]);  outputs [B, K, H, W] (channel 0 = background, 1..n = objects,
+//   the rest absent: em = 0 -> clamp -> logit = log(1e-7 / (1 - 1e-7))).
+__device__ inline float fg_prob(const float* __restrict__ dec, size_t plane, size_t pix) {
+  const float z0 = dec[pix], z1 = dec[plane + pix];
+  const float m = fmaxf(z0, z1);
+  const float e0 = expf(z0 - m), e1 = expf(z1 - m);
+  return e1 / (e0 + e1);
+}
+__device__ inline float em_logit(float em) {
+  em = fminf(fmaxf(em, 1e-7f), 1.0f - 1e-7f);
+  return logf(em / (1.0f - em));
+}
+
+__global__ __launch_bounds__(kThreads) void soft_aggregate(const float* __restrict__ dec,
+                                                           const int32_t* __restrict__ obj_begin,
+                                                           int K, int Hp, int Wp, int pad_l,
+                                                           int pad_t, int H, int W,
+                                                           float* __restrict__ logit,
+                                                           float* __restrict__ prob) {
+  const int b = blockIdx.y;
+  const int o0 = obj_begin[b], n = min(obj_begin[b + 1] - o0, K - 1);
+  const size_t plane = (size_t)Hp * Wp, oplane = (size_t)H * W;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < (long long)oplane;
+       i += (long long)gridDim.x * kThreads) {
+    const int y = (int)(i / W), x = (int)(i - (long long)y * W);
+    const size_t pix = (size_t)(y + pad_t) * Wp + (x + pad_l);
+    const float* d = dec + (size_t)o0 * 2 * plane;
+    float* lo = logit + (size_t)b * K * oplane + i;
+    float bg = 1.0f, mx = 0.0f;
+    for (int o = 0; o < n; ++o) {
+      const float p = fg_prob(d + (size_t)o * 2 * plane, plane, pix);
+      bg = bg * (1.0f - p);
+      const float l = em_logit(p);
+      lo[(size_t)(o + 1) * oplane] = l;
+      mx = o == 0 ? l : fmaxf(mx, l);
+    }
+    const float l0 = em_logit(bg), labs = em_logit(0.0f);
+    lo[0] = l0;
+    for (int k = n + 1; k < K; ++k) lo[(size_t)k * oplane] = labs;
+    if (prob) {   // soft-max over the K channels (models/rmnet.py:450)
+      mx = n > 0 ? fmaxf(mx, l0) : l0;
+      if (n + 1 < K) mx = fmaxf(mx, labs);
+      float sum = expf(l0 - mx);
+      const float eabs = expf(labs - mx);
+      for (int k = n + 1; k < K; ++k) sum += eabs;
+      for (int o = 0; o < n; ++o) sum += expf(lo[(size_t)(o + 1) * oplane] - mx);
+      float* po = prob + (size_t)b * K * oplane + i;
+      po[0] = expf(l0 - mx) / sum;
+      for (int o = 0; o < n; ++o) po[(size_t)(o + 1) * oplane] = expf(lo[(size_t)(o + 1) * oplane] - mx) / sum;
+      for (int k = n + 1; k < K; ++k) po[(size_t)k * oplane] = eabs / sum;
+    }
+  }
+}
+
 }  // namespace
 
 int launch_channel_affine(const float* x, const float* scale, const float* shift, const float* res,
@@ -175,6 +235,19 @@ int launch_upsample2x_add(const float* x, const float* skip, long long N, int C,
   if (vec) { if (skip) RMNET_UP(true, true); else RMNET_UP(true, false); }
   else     { if (skip) RMNET_UP(false, true); else RMNET_UP(false, false); }
 #undef RMNET_UP
+  return check_launch();
+}
+
+int launch_soft_aggregate(const float* dec, const int32_t* obj_begin, int B, int K, int Hp, int Wp,
+                          int pad_l, int pad_t, int H, int W, float* logit, float* prob,
+                          hipStream_t st) {
+  if (!dec || !obj_begin || !logit || B <= 0 || K <= 0 || H <= 0 || W <= 0) return RMNET_E_INVALID_ARG;
+  if (pad_l < 0 || pad_t < 0 || pad_l + W > Wp || pad_t + H > Hp) return RMNET_E_INVALID_ARG;
+  if (B > 65535) return RMNET_E_UNSUPPORTED;
+  long long chunks = ((long long)H * W + kThreads - 1) / kThreads;
+  if (chunks > 1024) chunks = 1024;
+  hipLaunchKernelGGL(soft_aggregate, dim3((unsigned)chunks, (unsigned)B), dim3(kThreads), 0, st, dec,
+                     obj_begin, K, Hp, Wp, pad_l, pad_t, H, W, logit, prob);
   return check_launch();
 }
 

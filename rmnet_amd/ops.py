@@ -276,6 +276,28 @@ def upsample2x_add(x, skip=None, out=None):
     return out
 
 
+def soft_aggregate(dec, obj_begin, K, pad, want_prob=False):
+    """Decoder logits [n_tot,2,Hp,Wp] -> (logit [B,K,H,W], prob [B,K,H,W] | None): 2-class soft-max,
+    soft aggregation (models/rmnet.py:289-302), un-pad by ``pad = (lw, uw, lh, uh)`` and, when asked,
+    the soft-max over the K channels, in one kernel.  ``obj_begin`` int32 [B+1] on the device."""
+    _check(dec, 'dec')
+    _check(obj_begin, 'obj_begin', torch.int32)
+    if dec.dim() != 4 or dec.shape[1] != 2:
+        raise RuntimeError('dec must be [n,2,Hp,Wp]')
+    B = obj_begin.numel() - 1
+    Hp, Wp = dec.shape[2:]
+    lw, uw, lh, uh = pad
+    H, W = Hp - lh - uh, Wp - lw - uw
+    logit = torch.empty(B, K, H, W, dtype=dec.dtype, device=dec.device)
+    prob = torch.empty_like(logit) if want_prob else None
+    lib = _lib.load()
+    with torch.cuda.device(dec.device):
+        rc = lib.rmnet_soft_aggregate_f32(_ptr(dec), _ptr(obj_begin), B, K, Hp, Wp, lw, lh, H, W,
+                                          _ptr(logit), _ptr(prob), _stream(dec.device))
+    _lib.check(rc, 'rmnet_soft_aggregate_f32')
+    return logit, prob
+
+
 def flow_affine(flow, m1, m2):
     """Device-resident variant: flow [H,W,2] f32 cuda, m1/m2 [2,3] f32 cuda -> [H,W,2]."""
     for t, n in ((flow, 'flow'), (m1, 'm1'), (m2, 'm2')):

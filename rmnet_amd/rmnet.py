@@ -93,6 +93,7 @@ class RMNet(nn.Module):
         from .networks import fuse_epilogues_
         self.eval()
         fuse_epilogues_(self, enable)
+        self._fused_tail = bool(enable)     # decoder tail: rmnet_soft_aggregate_f32 (frame loop only)
         return self
 
     # ------------------------------------------------------------------ small helpers
@@ -192,9 +193,11 @@ class RMNet(nn.Module):
         em = torch.clamp(em, 1e-7, 1 - 1e-7)
         return torch.log(em / (1 - em))
 
-    def _segment_core(self, frame, qry_rects, m_key, m_val, mem_rects, T, n_objects, K, batch_of_obj):
+    def _segment_core(self, frame, qry_rects, m_key, m_val, mem_rects, T, n_objects, K, batch_of_obj,
+                      obj_begin=None):
         """Everything of ``segment`` after the box bookkeeping: query encoder, fused regional read,
-        decoder, soft aggregation, un-pad."""
+        decoder, soft aggregation, un-pad.  With ``obj_begin`` (device int32 [B+1]) and
+        ``fuse_epilogues()`` the tail is one kernel and the return value is (logit, prob)."""
         (frame,), pad = pad_divide_by([frame], 16, frame.shape[2:])
         r4, r3, r2, _, _ = self.encoder_query(frame)
         k4, v4 = self.kv_query(r4)
@@ -209,6 +212,8 @@ class RMNet(nn.Module):
         else:                                       # reference-layout fp32 tensors (public segment())
             m4, _ = ops.memory_read(m_key, m_val, k4e.contiguous(), v4e.contiguous(), mem_rects, qry_rects,
                                     T=T, events=ev)
+        if obj_begin is not None and getattr(self, '_fused_tail', False):
+            return ops.soft_aggregate(self.decoder(m4, r3e, r2e).contiguous(), obj_begin, K, pad, want_prob=True)
         ps = F.softmax(self.decoder(m4, r3e, r2e), dim=1)[:, 1]
         logit = self.soft_aggregation(ps, K, n_objects)
         lw, uw, lh, uh = pad
@@ -242,6 +247,10 @@ class RMNet(nn.Module):
             self.lw, self.lh = lw, lh
             self.h, self.w = (H + lh + uh) // 16, (W + lw + uw) // 16
             self.device = device
+            begin = [0]
+            for n in self.n_max:
+                begin.append(begin[-1] + n)
+            self.obj_begin = torch.tensor(begin, dtype=torch.int32, device=device)
 
     def new_bank(self, ctx, capacity):
         """Pre-allocated regional memory for one clip (replaces models/rmnet.py:191-205, 416-426)."""
@@ -250,7 +259,8 @@ class RMNet(nn.Module):
     def frame_step(self, ctx, bank, prev_frame, prev_mask, cur_frame, cur_flow, commit):
         """One iteration of models/rmnet.py:410-433: memorise frame t-1 (tentatively, or for good
         when ``commit``), derive the regional query boxes from the flow-warped previous mask, segment
-        frame t.  Returns the logits [B,K,H,W].  No host synchronisation."""
+        frame t.  Returns the logits [B,K,H,W] -- or, after ``fuse_epilogues()``, the pair
+        (logits, soft-max over K of the logits).  No host synchronisation."""
         B, K = ctx.B, ctx.K
         k4, v4, boxes, rects = self._encode_memory(prev_frame, prev_mask, ctx.n_max)
         T = bank.stage(k4.contiguous(), v4.contiguous(), rects.view(B * K, 4).index_select(0, ctx.flat))
@@ -260,7 +270,8 @@ class RMNet(nn.Module):
         _, _, q_rects = ops.region_map(expt.contiguous(), want_map=False,
                                        cell_grid=(ctx.lw, ctx.lh, 16, ctx.h, ctx.w))
         q_rects = q_rects.view(B * K, 4).index_select(0, ctx.flat)
-        return self._segment_core(cur_frame, q_rects, bank, None, None, T, ctx.n_max, K, ctx.batch_of_obj)
+        return self._segment_core(cur_frame, q_rects, bank, None, None, T, ctx.n_max, K, ctx.batch_of_obj,
+                                  obj_begin=ctx.obj_begin)
 
     def forward(self, frames, masks, optical_flows, n_objects, memorize_every, device=None):
         """models/rmnet.py:385-452.  frames [B,N,3,H,W] f32, masks [B,N,K,H,W] (one-hot, any int or
@@ -287,7 +298,11 @@ class RMNet(nn.Module):
         for t in range(1, N):
             logit = self.frame_step(ctx, bank, frames[:, t - 1], est[:, t - 1], frames[:, t],
                                     optical_flows[:, t], (t - 1) in commit)
+            prob = None
+            if isinstance(logit, tuple):
+                logit, prob = logit     # fused tail: soft-max already done (valid if the logits stay as they are)
             if t in fresh:      # models/rmnet.py:436-441
+                prob = None
                 for b in range(B):
                     for j in torch.unique(torch.argmax(masks_dev[b, t], dim=0)).tolist():
                         if j not in existing[b]:
@@ -297,5 +312,6 @@ class RMNet(nn.Module):
                 missing = [j for j in range(n_max[b] + 1) if j not in existing[b]]
                 if missing:
                     logit[b, missing] = _ABSENT_LOGIT
-            est[:, t] = F.softmax(logit, dim=1)
+                    prob = None
+            est[:, t] = F.softmax(logit, dim=1) if prob is None else prob
         return est

@@ -631,3 +631,31 @@ def test_upsample2x_add_is_torch_bilinear(N, C, h, w):
     assert ops.upsample2x_add(x, t, out=t) is t and torch.equal(t, got)        # in place on the skip
     with pytest.raises(RuntimeError):
         ops.upsample2x_add(x, s[:, :, :-1].contiguous())
+
+
+@pytest.mark.parametrize('counts,K,Hp,Wp,pad', [([1], 2, 32, 48, (0, 0, 0, 0)), ([2, 1, 3], 5, 48, 64, (5, 5, 3, 2)),
+                                                 ([1, 1, 1, 1], 2, 480, 864, (5, 5, 0, 0)), ([0, 2], 4, 16, 16, (1, 0, 0, 1))])
+def test_soft_aggregate_matches_the_module_graph(counts, K, Hp, Wp, pad, oracle_mod):
+    """rmnet_soft_aggregate_f32 == softmax(dec)[:, 1] -> RMNet.soft_aggregation -> un-pad (-> softmax)
+    evaluated by torch (models/rmnet.py:368-380, 289-302, 450), incl. clips with no object and
+    absent channels."""
+    import torch.nn.functional as F
+    from rmnet_amd import ops
+    from rmnet_amd.rmnet import RMNet
+    g = torch.Generator().manual_seed(sum(counts) * 10 + K)
+    n = sum(counts)
+    dec = (torch.randn(max(n, 1), 2, Hp, Wp, generator=g) * 4).to(dev())[:n].contiguous()
+    begin = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32, device=dev())
+    lw, uw, lh, uh = pad
+    net = RMNet(None)
+    if n:
+        ps = F.softmax(dec, dim=1)[:, 1]
+    else:
+        ps = dec.new_zeros(0, Hp, Wp)
+    want = net.soft_aggregation(ps, K, counts)[:, :, lh:Hp - uh, lw:Wp - uw]
+    logit, prob = ops.soft_aggregate(dec if n else dec.new_zeros(1, 2, Hp, Wp), begin, K, pad, want_prob=True)
+    assert logit.shape == want.shape
+    np.testing.assert_allclose(logit.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(prob.cpu().numpy(), F.softmax(want, dim=1).cpu().numpy(), rtol=2e-5, atol=1e-6)
+    only, none = ops.soft_aggregate(dec if n else dec.new_zeros(1, 2, Hp, Wp), begin, K, pad)
+    assert none is None and torch.equal(only, logit)
