@@ -62,6 +62,19 @@ int rmnet_region_map_f32(const float *mask, int B, int K, int H, int W, float pr
                          int cell_stride, int cells_h, int cells_w, void *workspace,
                          size_t workspace_bytes, void *stream);
 
+/* A1 + G1 fused: the boxes of the FLOW-WARPED previous mask,
+ *   RMNet.get_att_map(prev_mask, flow) = att_map_generator(warp(prev_mask, flow))
+ * (models/rmnet.py:252-287), without materialising the warped mask: flow [B,2,H,W] fp32 (x then y
+ * displacement in pixels), everything else as rmnet_region_map_f32.  The warp follows the arithmetic
+ * PyTorch-ROCm executes for warp(): bilinear, align_corners=True, zero padding, validity of the
+ * sampling footprint thresholded at 0.9999.  `warped` (optional, [B,K,H,W], channel 0 untouched)
+ * receives the warped mask itself.  Same workspace size as rmnet_region_map_f32. */
+int rmnet_region_map_warped_f32(const float *mask, const float *flow, int B, int K, int H, int W,
+                                float prob_threshold, int n_pts_threshold, int n_bbox_loose_pixels,
+                                float *att_map, int32_t *bboxes, int32_t *cell_rects, int pad_l,
+                                int pad_t, int cell_stride, int cells_h, int cells_w, float *warped,
+                                void *workspace, size_t workspace_bytes, void *stream);
+
 /* Box -> cell rectangle only (same formula as above), for boxes already on the device. */
 int rmnet_boxes_to_cell_rects_i32(const int32_t *bboxes, int n_boxes, int k_per_batch, int pad_l,
                                   int pad_t, int cell_stride, int cells_h, int cells_w,

@@ -131,6 +131,18 @@ int rmnet_soft_aggregate_f32(const float* dec, const int32_t* obj_begin, int B, 
                                static_cast<hipStream_t>(stream));
 }
 
+int rmnet_region_map_warped_f32(const float* mask, const float* flow, int B, int K, int H, int W,
+                                float prob_threshold, int n_pts_threshold, int n_bbox_loose_pixels,
+                                float* att_map, int32_t* bboxes, int32_t* cell_rects, int pad_l,
+                                int pad_t, int cell_stride, int cells_h, int cells_w, float* warped,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  if (!flow) return RMNET_E_INVALID_ARG;
+  return launch_region_map_warped(mask, flow, B, K, H, W, prob_threshold, n_pts_threshold,
+                                  n_bbox_loose_pixels, att_map, bboxes, cell_rects, pad_l, pad_t,
+                                  cell_stride, cells_h, cells_w, warped, workspace, workspace_bytes,
+                                  static_cast<hipStream_t>(stream));
+}
+
 int rmnet_flow_affine_f32(const float* flow, const float* m1, const float* m2, int H, int W,
                           float* out, void* stream) {
   return launch_flow_affine(flow, m1, m2, H, W, out, static_cast<hipStream_t>(stream));

@@ -54,6 +54,10 @@ __device__ inline int wave_max(int v) {
 }
 
 // Launchers (one per .hip file); each returns RMNET_OK or a negative code.
+int launch_region_map_warped(const float* mask, const float* flow, int B, int K, int H, int W,
+                             float thr, int n_pts, int loose, float* att, int32_t* bboxes,
+                             int32_t* cell_rects, int pad_l, int pad_t, int cell_stride, int ch,
+                             int cw, float* warped, void* ws, size_t ws_bytes, hipStream_t st);
 int launch_region_map(const float* mask, int B, int K, int H, int W, float thr, int n_pts,
                       int loose, float* att, int32_t* bboxes, int32_t* cell_rects, int pad_l,
                       int pad_t, int cell_stride, int ch, int cw, void* ws, size_t ws_bytes,

@@ -133,6 +133,127 @@ __global__ __launch_bounds__(kThreads) void region_reduce(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Flow warp fused into the reduction.  RMNet.get_att_map (models/rmnet.py:280-287)
+// warps the previous soft mask along the optical flow (warp(), :252-278: base grid + flow, normalise
+// to [-1, 1], two grid_samples -- the mask and a validity map of ones -- threshold the validity at
+// 0.9999, multiply) only to feed the >= threshold count / min / max above; the module graph runs ~14
+// kernels and three full-resolution intermediates for it.  Here a lane evaluates the warped value of
+// its pixel in registers and reduces it straight away.  The arithmetic follows what PyTorch-ROCm
+// executes for that Python, operation by operation:
+//   v  = x + flow                       (fp32 add of the integer grid)
+//   g  = 2 * v * (1 / (W - 1)) - 1      (tensor / Python-scalar is a multiply by the fp32 reciprocal
+//                                        in ATen's CUDA/HIP div kernel)
+//   i  = ((g + 1) / 2) * (W - 1)        grid_sampler_unnormalize, align_corners = True
+//   corner weights (ix_se - ix) * (iy_se - iy) ..., accumulation in the order nw, ne, sw, se with the
+//   fused multiply-adds hipcc contracts in ATen's grid_sampler_2d_kernel (RMNET_WARP_FMA = 1; the GPU
+//   test compares bit for bit against torch, so a change of that build detail is caught),
+//   zero padding; validity = the same sum with ones; out = value * (validity >= 0.9999).
+#pragma clang fp contract(off)
+#ifndef RMNET_WARP_FMA
+#define RMNET_WARP_FMA 1
+#endif
+__device__ inline float warp_value(const float* __restrict__ m, int H, int W, int x, int y,
+                                   float fx, float fy, float inv_w, float inv_h) {
+  const float vx = (float)x + fx, vy = (float)y + fy;
+  const float gx = 2.0f * vx * inv_w - 1.0f;
+  const float gy = 2.0f * vy * inv_h - 1.0f;
+  const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
+  const float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+  const int ix_nw = (int)floorf(ix), iy_nw = (int)floorf(iy);
+  const int ix_se = ix_nw + 1, iy_se = iy_nw + 1;
+  const float nw = ((float)ix_se - ix) * ((float)iy_se - iy);
+  const float ne = (ix - (float)ix_nw) * ((float)iy_se - iy);
+  const float sw = ((float)ix_se - ix) * (iy - (float)iy_nw);
+  const float se = (ix - (float)ix_nw) * (iy - (float)iy_nw);
+  float acc = 0.0f, ones = 0.0f;
+  auto tap = [&](int yy, int xx, float wgt) {
+    if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
+      const float v = m[(size_t)yy * W + xx];
+#if RMNET_WARP_FMA
+      acc = __builtin_fmaf(v, wgt, acc);
+#else
+      acc = acc + v * wgt;
+#endif
+      ones = ones + wgt;
+    }
+  };
+  tap(iy_nw, ix_nw, nw);
+  tap(iy_nw, ix_se, ne);
+  tap(iy_se, ix_nw, sw);
+  tap(iy_se, ix_se, se);
+  return acc * (ones >= 0.9999f ? 1.0f : 0.0f);
+}
+
+__global__ __launch_bounds__(kThreads) void region_reduce_warped(const float* __restrict__ mask,
+                                                                 const float* __restrict__ flow,
+                                                                 int K, int H, int W, float thr,
+                                                                 float inv_w, float inv_h,
+                                                                 int rows_per_chunk,
+                                                                 Partial* __restrict__ partials,
+                                                                 float* __restrict__ warped) {
+  const int chunk = blockIdx.x, k = blockIdx.y + 1, b = blockIdx.z;
+  const int nchunks = gridDim.x;
+  const float* m = mask + ((size_t)b * K + k) * (size_t)H * W;
+  const float* fxp = flow + (size_t)b * 2 * H * W;
+  const float* fyp = fxp + (size_t)H * W;
+  float* wout = warped ? warped + ((size_t)b * K + k) * (size_t)H * W : nullptr;
+  const int r0 = chunk * rows_per_chunk;
+  const int r1 = min(H, r0 + rows_per_chunk);
+  const int wave_id = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  int n = 0, x0 = 32767, x1 = 0, y0 = 32767, y1 = 0;  // .cu:31-34 sentinels
+  for (int y = r0 + wave_id; y < r1; y += kThreads / RMNET_WAVE) {
+    int hit_lo = 32767, hit_hi = -1;
+    for (int base = 0; base < W; base += 4 * RMNET_WAVE) {
+      float fx[4], fy[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int x = base + u * RMNET_WAVE + ln;
+        fx[u] = x < W ? fxp[(size_t)y * W + x] : 0.0f;
+        fy[u] = x < W ? fyp[(size_t)y * W + x] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int x = base + u * RMNET_WAVE + ln;
+        if (x < W) {
+          const float v = warp_value(m, H, W, x, y, fx[u], fy[u], inv_w, inv_h);
+          if (wout) wout[(size_t)y * W + x] = v;
+          if (v >= thr) {
+            ++n;
+            hit_lo = min(hit_lo, x);
+            hit_hi = max(hit_hi, x);
+          }
+        }
+      }
+    }
+    if (hit_hi >= 0) {
+      x0 = min(x0, hit_lo);
+      x1 = max(x1, hit_hi);
+      y0 = min(y0, y);
+      y1 = max(y1, y);
+    }
+  }
+  fold(n, x0, x1, y0, y1);
+  __shared__ int red[kThreads / RMNET_WAVE][5];
+  if (ln == 0) {
+    red[wave_id][0] = n; red[wave_id][1] = x0; red[wave_id][2] = x1; red[wave_id][3] = y0; red[wave_id][4] = y1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 1; i < kThreads / RMNET_WAVE; ++i) {
+      n += red[i][0];
+      x0 = min(x0, red[i][1]);
+      x1 = max(x1, red[i][2]);
+      y0 = min(y0, red[i][3]);
+      y1 = max(y1, red[i][4]);
+    }
+    Partial p{n, x0, x1, y0, y1, 0, 0, 0};
+    partials[((size_t)b * K + k) * nchunks + chunk] = p;
+  }
+}
+#pragma clang fp contract(fast)
+
 // Threshold / loosen / clamp rule of .cu:55-77, integer-exact.
 __device__ inline void finalize_box(int n, int& x0, int& x1, int& y0, int& y1, int H, int W,
                                     int n_pts, int loose) {
@@ -262,6 +383,14 @@ int launch_region_map(const float* mask, int B, int K, int H, int W, float thr, 
                       int loose, float* att, int32_t* bboxes, int32_t* cell_rects, int pad_l,
                       int pad_t, int cell_stride, int ch, int cw, void* ws, size_t ws_bytes,
                       hipStream_t st) {
+  return launch_region_map_warped(mask, nullptr, B, K, H, W, thr, n_pts, loose, att, bboxes, cell_rects,
+                                  pad_l, pad_t, cell_stride, ch, cw, nullptr, ws, ws_bytes, st);
+}
+
+int launch_region_map_warped(const float* mask, const float* flow, int B, int K, int H, int W,
+                             float thr, int n_pts, int loose, float* att, int32_t* bboxes,
+                             int32_t* cell_rects, int pad_l, int pad_t, int cell_stride, int ch,
+                             int cw, float* warped, void* ws, size_t ws_bytes, hipStream_t st) {
   if (!mask || !bboxes || B <= 0 || K <= 0 || H <= 0 || W <= 0 || H > 32767 || W > 32767)
     return RMNET_E_INVALID_ARG;
   if (cell_rects && (cell_stride <= 0 || ch <= 0 || cw <= 0)) return RMNET_E_INVALID_ARG;
@@ -271,7 +400,14 @@ int launch_region_map(const float* mask, int B, int K, int H, int W, float thr, 
   const int rows = (H + chunks - 1) / chunks;
   Partial* partials = static_cast<Partial*>(ws);
   const bool vec_in = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(mask) & 15) == 0);
-  if (K > 1) {
+  if (warped && !flow) return RMNET_E_INVALID_ARG;
+  if (K > 1 && flow) {
+    dim3 g(chunks, K - 1, B);
+    const float inv_w = 1.0f / (float)(W > 1 ? W - 1 : 1), inv_h = 1.0f / (float)(H > 1 ? H - 1 : 1);
+    hipLaunchKernelGGL(region_reduce_warped, g, dim3(kThreads), 0, st, mask, flow, K, H, W, thr, inv_w,
+                       inv_h, rows, partials, warped);
+    if (int e = check_launch()) return e;
+  } else if (K > 1) {
     dim3 g(chunks, K - 1, B);
     if (vec_in)
       hipLaunchKernelGGL(region_reduce<true>, g, dim3(kThreads), 0, st, mask, K, H, W, thr, rows,

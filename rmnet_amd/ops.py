@@ -40,14 +40,22 @@ def _ws(nbytes, dev):
 
 
 def region_map(mask, prob_threshold=0.5, n_pts_threshold=10, n_bbox_loose_pixels=64,
-               want_map=True, cell_grid=None):
+               want_map=True, cell_grid=None, flow=None, want_warped=False):
     """mask [B,K,H,W] f32 cuda -> (att_map [B,K,H,W] f32 | None, bboxes [B,K,4] i32, rects | None).
 
     ``cell_grid = (pad_l, pad_t, stride, cells_h, cells_w)`` additionally returns the boxes as cell
-    rectangles on the 1/stride feature grid (see include/rmnet_hip.h)."""
+    rectangles on the 1/stride feature grid (see include/rmnet_hip.h).
+    ``flow`` [B,2,H,W]: the boxes are those of the flow-warped mask (RMNet.get_att_map with a flow,
+    models/rmnet.py:252-287), computed without materialising it; with ``want_warped`` the warped mask
+    (channels 1..K-1; channel 0 is zero) is returned as a fourth value."""
     _check(mask, 'mask')
     if mask.dim() != 4:
         raise RuntimeError('mask must be [B, K, H, W]')
+    if flow is not None:
+        return _region_map_warped(mask, flow, prob_threshold, n_pts_threshold, n_bbox_loose_pixels,
+                                  want_map, cell_grid, want_warped)
+    if want_warped:
+        raise RuntimeError('want_warped needs a flow')
     lib = _lib.load()
     B, K, H, W = mask.shape
     dev = mask.device
@@ -64,6 +72,31 @@ def region_map(mask, prob_threshold=0.5, n_pts_threshold=10, n_bbox_loose_pixels
                                       int(cw), _ptr(ws), ws.numel(), _stream(dev))
     _lib.check(rc, 'rmnet_region_map_f32')
     return att, bboxes, rects
+
+
+def _region_map_warped(mask, flow, prob_threshold, n_pts_threshold, n_bbox_loose_pixels, want_map,
+                       cell_grid, want_warped):
+    _check(flow, 'flow')
+    B, K, H, W = mask.shape
+    if tuple(flow.shape) != (B, 2, H, W):
+        raise RuntimeError('flow must be [B, 2, H, W]')
+    lib = _lib.load()
+    dev = mask.device
+    with torch.cuda.device(dev):
+        att = torch.empty_like(mask) if want_map else None
+        bboxes = torch.empty(B, K, 4, dtype=torch.int32, device=dev)
+        rects = torch.empty(B, K, 4, dtype=torch.int32, device=dev) if cell_grid is not None else None
+        warped = torch.zeros_like(mask) if want_warped else None
+        pl, pt, st, ch, cw = cell_grid if cell_grid is not None else (0, 0, 16, 1, 1)
+        nb = lib.rmnet_region_map_workspace_bytes(B, K, H, W)
+        ws = _ws(nb, dev)
+        rc = lib.rmnet_region_map_warped_f32(_ptr(mask), _ptr(flow), B, K, H, W, float(prob_threshold),
+                                             int(n_pts_threshold), int(n_bbox_loose_pixels), _ptr(att),
+                                             _ptr(bboxes), _ptr(rects), int(pl), int(pt), int(st),
+                                             int(ch), int(cw), _ptr(warped), _ptr(ws), ws.numel(),
+                                             _stream(dev))
+    _lib.check(rc, 'rmnet_region_map_warped_f32')
+    return (att, bboxes, rects, warped) if want_warped else (att, bboxes, rects)
 
 
 def boxes_to_cell_rects(bboxes, pad_l, pad_t, stride, cells_h, cells_w, k_per_batch=0):

@@ -266,9 +266,13 @@ class RMNet(nn.Module):
         T = bank.stage(k4.contiguous(), v4.contiguous(), rects.view(B * K, 4).index_select(0, ctx.flat))
         if commit:
             bank.commit()
-        expt = self.warp(prev_mask, cur_flow)[0]            # models/rmnet.py:429-431
-        _, _, q_rects = ops.region_map(expt.contiguous(), want_map=False,
-                                       cell_grid=(ctx.lw, ctx.lh, 16, ctx.h, ctx.w))
+        if getattr(self, '_fused_tail', False):             # warp fused into the box reduction
+            _, _, q_rects = ops.region_map(prev_mask.contiguous(), want_map=False, flow=cur_flow.contiguous(),
+                                           cell_grid=(ctx.lw, ctx.lh, 16, ctx.h, ctx.w))
+        else:
+            expt = self.warp(prev_mask, cur_flow)[0]        # models/rmnet.py:429-431
+            _, _, q_rects = ops.region_map(expt.contiguous(), want_map=False,
+                                           cell_grid=(ctx.lw, ctx.lh, 16, ctx.h, ctx.w))
         q_rects = q_rects.view(B * K, 4).index_select(0, ctx.flat)
         return self._segment_core(cur_frame, q_rects, bank, None, None, T, ctx.n_max, K, ctx.batch_of_obj,
                                   obj_begin=ctx.obj_begin)

@@ -659,3 +659,28 @@ def test_soft_aggregate_matches_the_module_graph(counts, K, Hp, Wp, pad, oracle_
     np.testing.assert_allclose(prob.cpu().numpy(), F.softmax(want, dim=1).cpu().numpy(), rtol=2e-5, atol=1e-6)
     only, none = ops.soft_aggregate(dec if n else dec.new_zeros(1, 2, Hp, Wp), begin, K, pad)
     assert none is None and torch.equal(only, logit)
+
+
+@pytest.mark.parametrize('B,K,H,W,amp', [(1, 2, 480, 854, 3.0), (2, 3, 97, 131, 8.0), (1, 4, 33, 47, 40.0), (1, 2, 1, 1, 0.3)])
+def test_region_map_of_the_warped_mask_is_bit_exact(B, K, H, W, amp):
+    """rmnet_region_map_warped_f32 == att_map_generator(RMNet.warp(mask, flow)) (models/rmnet.py:252-287):
+    the warped mask it evaluates in registers is bit-identical to the one torch computes on the same
+    GPU (grid build, two grid_samples, validity threshold), hence so are the integer boxes and cell
+    rectangles -- including flows that leave the frame."""
+    from rmnet_amd import ops
+    from rmnet_amd.rmnet import RMNet
+    net = RMNet(None)
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    m = torch.rand(B, K, H, W, generator=g).to(dev())
+    f = (torch.randn(B, 2, H, W, generator=g) * amp).to(dev())
+    f[:, :, : max(1, H // 8)] += 2.0 * max(H, W)              # a band sampled far outside: validity 0
+    want = net.warp(m, f)[0].contiguous()
+    grid = (3, 1, 16, (H + 15) // 16 + 1, (W + 15) // 16 + 1)
+    att0, bb0, rc0 = ops.region_map(want, cell_grid=grid)
+    att1, bb1, rc1, got = ops.region_map(m, cell_grid=grid, flow=f, want_warped=True)
+    assert torch.equal(got[:, 1:], want[:, 1:]) and float(got[:, 0].abs().max()) == 0.0
+    assert torch.equal(bb0, bb1) and torch.equal(rc0, rc1) and torch.equal(att0, att1)
+    _, bb2, _ = ops.region_map(m, want_map=False, flow=f)                      # without the extra output
+    assert torch.equal(bb2, bb0)
+    with pytest.raises(RuntimeError):
+        ops.region_map(m, flow=f[:, :1].contiguous())
