@@ -98,3 +98,21 @@ def test_two_rank_gather_gloo():
     assert shapes == [(5, 4, 6), (3, 5, 6), (4, 6, 6), (2, 7, 6), (6, 8, 6)]
     assert means == [1, 11, 21, 31, 41]
     assert mx == 2.0 and sm == 4.0
+
+
+def test_device_side_jaccard_matches_the_reference_definition(oracle_mod):
+    """rmnet_amd.metrics (utils/metrics.py:84-102 as tensor ops) vs the oracle's scalar restatement,
+    incl. the both-empty -> 1 rule."""
+    from rmnet_amd import metrics
+    rng = np.random.RandomState(5)
+    N, H, W, n = 4, 17, 23, 3
+    pred = rng.randint(0, n + 1, size=(N, H, W))
+    gt = rng.randint(0, n + 1, size=(N, H, W))
+    pred[2][pred[2] == 2] = 0
+    gt[2][gt[2] == 2] = 0                    # object 2 absent in both at frame 2
+    j = metrics.jaccard_per_object(torch.from_numpy(pred), torch.from_numpy(gt), n).numpy()
+    for t in range(N):
+        for o in range(1, n + 1):
+            assert abs(j[t, o - 1] - oracle_mod.iou(pred[t] == o, gt[t] == o)) < 1e-12
+    assert j[2, 1] == 1.0
+    assert abs(float(metrics.mean_jaccard(torch.from_numpy(pred), torch.from_numpy(gt), n)) - j[1:-1].mean()) < 1e-12
