@@ -13,7 +13,7 @@
 //                   with 16-byte loads (one row per block iteration, so x needs no division),
 //                   reduces {count, min/max x, min/max y} in registers -> wave shuffles -> LDS,
 //                   and writes ONE 5-int partial record.  Deterministic, no init pass needed.
-//   region_fill   : grid (chunks, K, B).  Every block folds the <= 64 partial records of its
+//   region_fill   : grid (chunks, K, B).  Every block folds the <= 256 partial records of its
 //                   channel (they are L2-resident), applies the threshold/loosen/clamp rule --
 //                   integer arithmetic, identical in every block -- and streams its band of the
 //                   0/1 map with 16-byte stores.  Block 0 of each channel also writes the box and,
@@ -27,7 +27,7 @@ namespace rmnet {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kMaxChunks = 64;  // partial records per channel; folded by one wave in region_fill
+constexpr int kMaxChunks = 256;  // partial records per channel; folded by one wave in region_fill
 
 struct Partial {
   int n, x0, x1, y0, y1, pad0, pad1, pad2;
@@ -280,9 +280,13 @@ __global__ __launch_bounds__(kThreads) void region_fill(const Partial* __restric
   __shared__ int box[4];
   if (threadIdx.x < RMNET_WAVE) {  // one wave folds the partial records
     int n = 0, x0 = 32767, x1 = 0, y0 = 32767, y1 = 0;
-    if (k > 0 && (int)threadIdx.x < n_part) {
-      const Partial p = partials[((size_t)b * K + k) * n_part + threadIdx.x];
-      n = p.n; x0 = p.x0; x1 = p.x1; y0 = p.y0; y1 = p.y1;
+    if (k > 0) {
+      for (int i = threadIdx.x; i < n_part; i += RMNET_WAVE) {   // <= kMaxChunks / 64 records per lane
+        const Partial p = partials[((size_t)b * K + k) * n_part + i];
+        n += p.n;
+        x0 = min(x0, p.x0); x1 = max(x1, p.x1);
+        y0 = min(y0, p.y0); y1 = max(y1, p.y1);
+      }
     }
     fold(n, x0, x1, y0, y1);
     if (k > 0) {
@@ -367,7 +371,7 @@ int chunks_for(int B, int K, int H) {
   const int planes = B * (K > 1 ? K - 1 : 1);
   int chunks = (1024 + planes - 1) / planes;
   if (chunks > kMaxChunks) chunks = kMaxChunks;
-  if (chunks > H) chunks = H;
+  if (chunks > (H + 3) / 4) chunks = (H + 3) / 4;   // >= 4 rows per block: one per wave
   if (chunks < 1) chunks = 1;
   return chunks;
 }
