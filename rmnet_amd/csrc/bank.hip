@@ -202,7 +202,9 @@ struct BArgs {
   float* ws_o;               // [no][slots] partial blocks in fragment order (common.h)
   float* ws_ml;              // [no][slots][2][kQT]: running reference (log2 domain) and sum
   int32_t* ws_plan;          // [no][kPlanInts]
-  int T, slots;
+  int T;
+  int obj0, nobj;            // objects [obj0, obj0 + nobj) belong to this launch (nobj <= kMaxObj)
+  int slot0, target;         // first partial slot of the launch; workgroups to aim for
   float qscale;              // log2(e) / sqrt(De), folded into the query fragments
 };
 
@@ -244,7 +246,9 @@ constexpr int kRThreads = 64 * (kProducers + kConsumers);  // 768 = 12 waves = 3
 //   producer chain = PV share + S + soft-max as the critical path of every tile, 2x the MFMA time.)
 //   ONE barrier per tile.
 struct Walk {          // per-workgroup constants of the tile walk (all wave-uniform)
-  int jt0, ntl, qt, L, Mq;
+  int jt0, ntl, qt, Mq;
+  int o;               // object (absolute index)
+  int slot;            // partial slot (absolute index)
   Rect qr;
   int t;               // frame of the first tile
 };
@@ -291,11 +295,11 @@ struct Cursor {
 __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
                                      const int* tpre, const int* tarea, int wave, int lane, long long t_entry) {
   const BankView& b = a.b;
-  const int o = blockIdx.y;
+  const int o = wk.o;
   const int l15 = lane & 15, g = lane >> 4;
   const int jt0 = wk.jt0, ntl = wk.ntl;
 #if BK_TRACE
-  long long* trc = reinterpret_cast<long long*>(a.ws_o + ((size_t)o * a.slots + (a.slots - 1)) * (size_t)kDo * kQT);
+  long long* trc = reinterpret_cast<long long*>(a.ws_o + (size_t)(a.slot0 + a.target - 1) * (size_t)kDo * kQT);
   int trn = 0;
   const bool trace_on = blockIdx.x == 0 && wave == 0 && lane == 0;
   if (trace_on) trc[trn++] = t_entry;
@@ -448,7 +452,7 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
     BK_STAMP();   // after barrier
   }
   if (g == 0 && !(BK_ABLATE & 8)) {
-    float* wm = a.ws_ml + ((size_t)o * a.slots + wk.L) * 2 * kQT;
+    float* wm = a.ws_ml + (size_t)wk.slot * 2 * kQT;
     wm[wave * 16 + l15] = mref;
     wm[kQT + wave * 16 + l15] = lsum;
   }
@@ -459,13 +463,13 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
 __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
                                      const int* tpre, int wave, int lane, long long t_entry) {
   const BankView& b = a.b;
-  const int o = blockIdx.y;
+  const int o = wk.o;
   const int l15 = lane & 15, g = lane >> 4;
   const int jt0 = wk.jt0, ntl = wk.ntl;
   const size_t so0 = (size_t)o * b.Tcap;
   const size_t tiles_per_slot = (size_t)(b.hwp / kJT);
 #if BK_TRACE
-  long long* trc = reinterpret_cast<long long*>(a.ws_o + ((size_t)o * a.slots + (a.slots - 1)) * (size_t)kDo * kQT) + 1024;
+  long long* trc = reinterpret_cast<long long*>(a.ws_o + (size_t)(a.slot0 + a.target - 1) * (size_t)kDo * kQT) + 1024;
   int trn = 0;
   const bool trace_on = blockIdx.x == 0 && wave == kProducers && lane == 0;
   if (trace_on) trc[trn++] = t_entry;
@@ -593,7 +597,7 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
 
   // ---- partial O -> workspace slot L in fragment order (common.h): 1 KB contiguous per store
   if (!(BK_ABLATE & 8)) {
-    float* wo = a.ws_o + ((size_t)o * a.slots + wk.L) * (size_t)kDo * kQT;
+    float* wo = a.ws_o + (size_t)wk.slot * (size_t)kDo * kQT;
 #pragma unroll
     for (int dt = 0; dt < kCDT; ++dt)
 #pragma unroll
@@ -606,8 +610,13 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
   BK_STAMP();   // epilogue stores drained
 }
 
+constexpr int kMaxObj = 64;    // objects planned together in one launch (the launcher groups more)
+
 __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+  __shared__ int o_njt[kMaxObj], o_m[kMaxObj], o_nqt[kMaxObj], o_ns[kMaxObj], o_base[kMaxObj];
+  __shared__ int o_rect[kMaxObj][4];
+  __shared__ int total_units;
   char* Kl_ = lds;                                 // [ring slot][plane][8 KB]
   char* Pl_ = lds + 8 * kKbuf;                     // [buf][ntile][plane][lane*16]
   float* Al = reinterpret_cast<float*>(Pl_ + 2 * kPbuf);
@@ -616,57 +625,140 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
 
   const long long t_entry = (long long)__builtin_readcyclecounter();
   const BankView& b = a.b;
-  const int tid = threadIdx.x, o = blockIdx.y;
+  const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool producer = wave < kProducers;
   if (producer && BK_PRIO > 0) __builtin_amdgcn_s_setprio(BK_PRIO);
 
-  // ---- plan: tile prefix over the T memorised frames, query rectangle, split decode.  The query
-  //      rectangle load is issued first so that its latency overlaps the area loads.
-  int q0 = 0, q1 = b.w - 1, q2 = 0, q3 = b.h - 1;
-  if (a.qry_rects) {
-    const int32_t* q = a.qry_rects + (size_t)o * 4;
-    q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+  // ---- launch-wide plan, computed identically by every workgroup from the device-resident boxes
+  //      (no host sync): per object the query tiles and memory tiles; ONE chunk length C for the
+  //      whole launch such that  sum_o nqt(o) * ceil(njt(o) / C)  workgroup units fill `target`
+  //      CUs; object o is cut into nsplit(o) = ceil(njt(o) / C) nearly equal splits.  Objects with
+  //      boxes of different sizes (multi-object clips, several clips per GPU) then finish together,
+  //      which a per-object  target / (nqt * no)  rule does not give.
+  const int ng = a.nobj;
+  const int lane0 = tid & 63;
+  // Fast path (<= 12 objects, <= 64 memorised frames): wave w owns object w, lane t its frame t; the
+  // areas stay in registers, so the owner wave later builds the workgroup's tile prefix without a
+  // second trip to memory.  Otherwise: LDS atomics now, a reload of the own object's areas later.
+  const bool fastplan = ng <= kProducers + kConsumers && a.T <= RMNET_WAVE;
+  int my_ar = 0;
+  if (fastplan) {
+    if (wave < ng && lane0 < a.T) my_ar = b.area[(size_t)(a.obj0 + wave) * b.Tcap + lane0];
+  } else if (tid < ng) {
+    o_njt[tid] = 0; o_m[tid] = 0;
   }
-  if (tid < RMNET_WAVE) {
+  if (tid < ng) {   // query rectangle -> compacted queries -> query tiles (+1: the mean slot)
+    int q0 = 0, q1 = b.w - 1, q2 = 0, q3 = b.h - 1;
+    if (a.qry_rects) {
+      const int32_t* q = a.qry_rects + (size_t)(a.obj0 + tid) * 4;
+      q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+    }
+    const Rect r{max(q0, 0), min(q1, b.w - 1), max(q2, 0), min(q3, b.h - 1)};
+    const int Mq = r.area();
+    o_rect[tid][0] = r.cx0; o_rect[tid][1] = r.cx1; o_rect[tid][2] = r.cy0; o_rect[tid][3] = r.cy1;
+    int nqt = (Mq + (Mq < b.hw ? 1 : 0) + kQT - 1) / kQT;
+    o_nqt[tid] = nqt < 1 ? 1 : nqt;
+  }
+  if (fastplan) {
+    const int tiles = wave_sum((my_ar + kJT - 1) / kJT), cells = wave_sum(my_ar);
+    if (lane0 == 0 && wave < ng) { o_njt[wave] = tiles; o_m[wave] = cells; }
+  } else {
+    __syncthreads();
+    for (int idx = tid; idx < ng * a.T; idx += kRThreads) {
+      const int og = idx / a.T, t = idx - og * a.T;
+      const int ar = b.area[(size_t)(a.obj0 + og) * b.Tcap + t];
+      atomicAdd(&o_njt[og], (ar + kJT - 1) / kJT);
+      atomicAdd(&o_m[og], ar);
+    }
+  }
+  __syncthreads();
+  if (tid < RMNET_WAVE) {   // one wave, lane = object
+    const int nqt = tid < ng ? o_nqt[tid] : 0, njt = tid < ng ? o_njt[tid] : 0;
+    const int work = wave_sum(nqt * njt);
+    const int nsmax = njt / kSplitMinTiles < 1 ? 1 : (njt / kSplitMinTiles > kSplitMax ? kSplitMax : njt / kSplitMinTiles);
+    int C = (work + a.target - 1) / a.target;
+    if (C < 1) C = 1;
+    int ns = 0;
+    for (int it = 0; it < 256; ++it) {
+      ns = njt == 0 ? 0 : (njt + C - 1) / C;
+      const bool capped = ns > nsmax;
+      if (capped) ns = nsmax;
+      (void)capped;
+      const int units = wave_sum(nqt * ns);
+      const int min_units = wave_sum(njt == 0 ? 0 : nqt);     // one split per pair
+      if (units <= a.target || units == min_units) break;     // fits, or cannot shrink any further
+      C += C >> 4 > 0 ? C >> 4 : 1;
+    }
+    int u = nqt * ns, incl = u;
+#pragma unroll
+    for (int d = 1; d < RMNET_WAVE; d <<= 1) {
+      const int up = __shfl_up(incl, d);
+      if (tid >= d) incl += up;
+    }
+    if (tid < ng) { o_ns[tid] = ns; o_base[tid] = incl - u; }
+    if (tid == RMNET_WAVE - 1) total_units = incl;
+  }
+  __syncthreads();
+  const int total = total_units;
+  if ((int)blockIdx.x < ng && tid == 0) {   // plan record of object blockIdx.x for the combine kernel
+    const int og = blockIdx.x;
+    int32_t* pr = a.ws_plan + (size_t)(a.obj0 + og) * kPlanInts;
+    const Rect r{o_rect[og][0], o_rect[og][1], o_rect[og][2], o_rect[og][3]};
+    pr[0] = r.area(); pr[1] = o_nqt[og]; pr[2] = o_ns[og]; pr[3] = o_m[og];
+    pr[4] = r.cx0; pr[5] = r.cx1; pr[6] = r.cy0; pr[7] = r.cy1;
+    pr[8] = a.slot0 + o_base[og];
+  }
+  if ((int)blockIdx.x >= total) return;
+  int U;
+  {
+    const int q8 = total >> 3, r8 = total & 7, x = blockIdx.x & 7;   // XCD-contiguous logical ids
+    U = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (blockIdx.x >> 3);
+  }
+  int og = 0;
+  for (int i = 1; i < ng; ++i)
+    if (o_base[i] <= U) og = i;             // (objects without units share the next one's base: the later one wins)
+  Walk wk;
+  wk.o = a.obj0 + og;
+  wk.slot = a.slot0 + U;
+  wk.qr = Rect{o_rect[og][0], o_rect[og][1], o_rect[og][2], o_rect[og][3]};
+  wk.Mq = wk.qr.area();
+  const int nqt = o_nqt[og], nsplit = o_ns[og], njt = o_njt[og];
+  const int L = U - o_base[og];
+  const int s = L / nqt;
+  wk.qt = L - s * nqt;
+  wk.jt0 = (int)(((long long)s * njt) / nsplit);
+  wk.ntl = (int)(((long long)(s + 1) * njt) / nsplit) - wk.jt0;
+
+  // ---- this object's tile prefix over the T memorised frames
+  if (fastplan) {
+    if (wave == og) {   // the wave that holds this object's areas
+      int sc = (my_ar + kJT - 1) / kJT;
+#pragma unroll
+      for (int d = 1; d < RMNET_WAVE; d <<= 1) {
+        const int up = __shfl_up(sc, d);
+        if (lane0 >= d) sc += up;
+      }
+      if (lane0 < a.T) { tpre[lane0 + 1] = sc; tarea[lane0] = my_ar; }
+      if (lane0 == 0) tpre[0] = 0;
+    }
+  } else if (tid < RMNET_WAVE) {
     int carry = 0;
     for (int base = 0; base < a.T; base += RMNET_WAVE) {
       const int t = base + tid;
-      const int ar = t < a.T ? b.area[(size_t)o * b.Tcap + t] : 0;
-      int s = (ar + kJT - 1) / kJT;
+      const int ar = t < a.T ? b.area[(size_t)wk.o * b.Tcap + t] : 0;
+      int sc = (ar + kJT - 1) / kJT;
 #pragma unroll
       for (int d = 1; d < RMNET_WAVE; d <<= 1) {
-        const int up = __shfl_up(s, d);
-        if (tid >= d) s += up;
+        const int up = __shfl_up(sc, d);
+        if (tid >= d) sc += up;
       }
-      if (t < a.T) { tpre[t + 1] = carry + s; tarea[t] = ar; }
-      carry += __shfl(s, RMNET_WAVE - 1);
+      if (t < a.T) { tpre[t + 1] = carry + sc; tarea[t] = ar; }
+      carry += __shfl(sc, RMNET_WAVE - 1);
     }
     if (tid == 0) tpre[0] = 0;
   }
   __syncthreads();
-  const int njt = tpre[a.T];
-  Walk wk;
-  wk.qr = Rect{max(q0, 0), min(q1, b.w - 1), max(q2, 0), min(q3, b.h - 1)};
-  wk.Mq = wk.qr.area();
-  const BankPlan pl = bank_plan(wk.Mq, b.hw, njt, b.no, a.slots);
-  const int nact = pl.nqt * pl.nsplit;
-  if (blockIdx.x == 0 && tid == 0) {   // plan record for the combine kernel
-    int m = 0;
-    for (int t = 0; t < a.T; ++t) m += tarea[t];
-    int32_t* pr = a.ws_plan + (size_t)o * kPlanInts;
-    pr[0] = wk.Mq; pr[1] = pl.nqt; pr[2] = pl.nsplit; pr[3] = m;
-    pr[4] = wk.qr.cx0; pr[5] = wk.qr.cx1; pr[6] = wk.qr.cy0; pr[7] = wk.qr.cy1;
-  }
-  if ((int)blockIdx.x >= nact) return;
-  {
-    const int q8 = nact >> 3, r8 = nact & 7, x = blockIdx.x & 7;   // XCD-contiguous logical ids
-    wk.L = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (blockIdx.x >> 3);
-  }
-  const int s = wk.L / pl.nqt;
-  wk.qt = wk.L - s * pl.nqt;
-  wk.jt0 = (int)(((long long)s * njt) / pl.nsplit);
-  wk.ntl = (int)(((long long)(s + 1) * njt) / pl.nsplit) - wk.jt0;
   {
     int lo = 0, hi = a.T;   // frame of the first tile
     while (hi - lo > 1) {
@@ -699,10 +791,23 @@ int launch_bank_main(const BankReadArgs& m, hipStream_t st) {
   a.b = bank_view(const_cast<void*>(m.bank), m.no, m.Tcap, m.h, m.w);
   a.qk = m.qk; a.qv = m.qv; a.qry_rects = m.qry_rects;
   a.ws_o = m.ws_o; a.ws_ml = m.ws_ml; a.ws_plan = m.ws_plan;
-  a.T = m.T; a.slots = m.slots;
+  a.T = m.T;
   a.qscale = 1.44269504088896341f / sqrtf((float)kDe);
-  hipLaunchKernelGGL(bk_main, dim3(m.slots, m.no), dim3(kRThreads), 0, st, a);
-  return check_launch();
+  // Objects are planned together in groups of <= kMaxObj; a group owns the partial slots
+  // [obj0 * slots, (obj0 + nobj) * slots), which always hold max(target, nobj * query tiles) units.
+  const int nqt_max = (m.h * m.w + 1 + kQT - 1) / kQT;
+  for (int obj0 = 0; obj0 < m.no; obj0 += kMaxObj) {
+    a.obj0 = obj0;
+    a.nobj = m.no - obj0 < kMaxObj ? m.no - obj0 : kMaxObj;
+    a.slot0 = obj0 * m.slots;
+    const long long cap = (long long)a.nobj * m.slots;
+    a.target = (int)(cap < kSplitTargetSlots ? cap : kSplitTargetSlots);
+    const int floor_units = a.nobj * nqt_max;
+    const int grid = a.target > floor_units ? a.target : floor_units;
+    hipLaunchKernelGGL(bk_main, dim3(grid), dim3(kRThreads), 0, st, a);
+    if (int e = check_launch()) return e;
+  }
+  return RMNET_OK;
 }
 
 }  // namespace rmnet

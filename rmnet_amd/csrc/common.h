@@ -137,9 +137,11 @@ __host__ __device__ inline BankPlan bank_plan(int Mq, int hw, int njt, int no, i
   return p;
 }
 
-// Plan record written by block 0 of a read kernel for the combine kernel (one 32-byte load instead of
-// re-deriving the plan from rectangles / areas): {Mq, nqt, nsplit, M, qr.cx0, qr.cx1, qr.cy0, qr.cy1}.
-constexpr int kPlanInts = 8;
+// Plan record written by a read kernel for the combine kernel (one small load instead of re-deriving
+// the plan from rectangles / areas): {Mq, nqt, nsplit, M, qr.cx0, qr.cx1, qr.cy0, qr.cy1, first
+// partial slot of the object, 0, 0, 0}; the partial of (split s, query tile qt) is slot
+// first + s * nqt + qt.
+constexpr int kPlanInts = 12;
 
 struct BankReadArgs {
   const void* bank;

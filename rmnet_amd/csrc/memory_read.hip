@@ -197,6 +197,7 @@ __global__ __launch_bounds__(kThreads, 1) void mr_main(const KArgs a) {
     int32_t* pr = a.ws_plan + (size_t)o * kPlanInts;
     pr[0] = pl.Mq; pr[1] = pl.nqt; pr[2] = pl.nsplit; pr[3] = pl.M;
     pr[4] = pl.qr.cx0; pr[5] = pl.qr.cx1; pr[6] = pl.qr.cy0; pr[7] = pl.qr.cy1;
+    pr[8] = o * a.slots;
   }
   if ((int)blockIdx.x >= nact) return;
   const int L = xcd_remap(blockIdx.x, nact);
@@ -365,7 +366,7 @@ constexpr int kCombDt = kCombCh / 16;    // = channel tiles (fragments) per quer
 // The bank kernel keeps its running reference in the log2 domain (2^x soft-max), mr_main in the
 // natural one; a.bank_area tells which.
 template <bool REGIONAL>
-__global__ __launch_bounds__(kThreads) void mr_combine(const KArgs a, int nqt_max) {
+__global__ __launch_bounds__(kThreads, 6) void mr_combine(const KArgs a, int nqt_max) {   // <= 80 VGPRs: 6 workgroups' worth of waves per SIMD hide this kernel's latency chains
   __shared__ float Wt[kMaxSplits][kQT];
   __shared__ float Wm[kMaxSplits];
   __shared__ float red[4][kQT];
@@ -373,17 +374,19 @@ __global__ __launch_bounds__(kThreads) void mr_combine(const KArgs a, int nqt_ma
   __shared__ float Tm[kCombCh];
   const int tid = threadIdx.x, o = blockIdx.z;
   Plan pl;
+  int slot_base;
   {
     const int32_t* pr = a.ws_plan + (size_t)o * kPlanInts;
     pl.Mq = pr[0]; pl.nqt = pr[1]; pl.nsplit = pr[2]; pl.M = pr[3];
     pl.qr = Rect{pr[4], pr[5], pr[6], pr[7]};
     pl.njt = 0;
+    slot_base = __builtin_amdgcn_readfirstlane(pr[8]);
   }
   const bool log2d = a.bank_area != nullptr;
   const int qi = tid & 63, sl = tid >> 6;
   const float n_out = (float)(a.T * a.hw - pl.M);
-  const float* __restrict__ ml = a.ws_ml + (size_t)o * a.slots * 2 * kQT;
-  const float* __restrict__ wo = a.ws_o + (size_t)o * a.slots * (size_t)kDo * kQT;
+  const float* __restrict__ ml = a.ws_ml + (size_t)slot_base * 2 * kQT;
+  const float* __restrict__ wo = a.ws_o + (size_t)slot_base * (size_t)kDo * kQT;
   const bool fill = (int)blockIdx.x >= nqt_max;   // masked-row filler block
   const bool masked = REGIONAL && pl.Mq < a.hw;   // some query cell is masked: a mean slot exists
   const int qt = (int)blockIdx.x;
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(kThreads) void mr_combine(const KArgs a, int nqt_ma
   // that their latency overlaps the (m, l) loads and the three barriers of the weight phase.
   // Thread = (query tile it = sl, lane qi) of the block's channel tiles; splits past the last one
   // are clamped (re-read) and get weight 0.
-  constexpr int kU = 16 / kCombDt;       // splits per batch: 16 independent 16-byte loads in flight
+  constexpr int kU = kCombDt >= 8 ? 1 : 8 / kCombDt;   // splits per batch: 8 independent 16-byte loads in flight
   constexpr int kE = kU < 4 ? kU : 4;    // splits of the early batch (small: duplicates cost bandwidth)
   const float* __restrict__ psrc = wo + (size_t)(fill ? 0 : qt) * kDo * kQT + partial_frag_offset(d0 >> 4, sl, qi);
   f32x4 v0[kE][kCombDt];

@@ -293,7 +293,10 @@ def _fill_bank(ops, mk, mv, mr, capacity=None):
 
 @pytest.mark.parametrize('no,T,h,w,regional', [
     (1, 1, 4, 5, False), (2, 3, 9, 13, True), (3, 2, 12, 20, True), (1, 5, 30, 54, True),
-    (1, 4, 8, 8, True), (1, 7, 16, 24, False), (2, 9, 10, 7, True)])
+    (1, 4, 8, 8, True), (1, 7, 16, 24, False), (2, 9, 10, 7, True),
+    (14, 2, 6, 9, True),      # > 12 objects: the launch plan's LDS-atomic path
+    (70, 1, 4, 5, True),      # > 64 objects: two launch groups
+    (5, 3, 30, 54, True)])    # boxes of very different sizes planned together
 def test_bank_read_vs_oracle(no, T, h, w, regional, oracle_mod):
     """The split-fp16 bank path (what the frame loop uses) against the oracle, same tolerance as the
     fp32-MFMA path."""
