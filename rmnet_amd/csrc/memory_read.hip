@@ -346,6 +346,9 @@ __global__ __launch_bounds__(kThreads, 1) void mr_main(const KArgs a) {
 #ifndef RMNET_COMB_CH
 #define RMNET_COMB_CH 16
 #endif
+#ifndef RMNET_COMB_ABL
+#define RMNET_COMB_ABL 0   // experiments: 1 no q_val half, 2 no mem-half stores, 4 no fill blocks, 8 no partial loads
+#endif
 constexpr int kCombCh = RMNET_COMB_CH;  // read-out channels (and as many q_val channels) per combine block
 constexpr int kCombDt = kCombCh / 16;    // = channel tiles (fragments) per query tile and split
 
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(kThreads, 6) void mr_combine(const KArgs a, int nqt
   const bool masked = REGIONAL && pl.Mq < a.hw;   // some query cell is masked: a mean slot exists
   const int qt = (int)blockIdx.x;
   if (!fill && qt >= pl.nqt) return;
-  if (fill && !masked) return;
+  if (fill && (!masked || (RMNET_COMB_ABL & 4))) return;
   const int n0 = qt * kQT, n1 = min(n0 + kQT, pl.Mq);   // this tile's real queries
   if (!fill && n1 <= n0) return;                        // the tile holds only the mean slot
   int fc0 = 0;
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(kThreads, 6) void mr_combine(const KArgs a, int nqt
   for (int u = 0; u < kE; ++u)
 #pragma unroll
     for (int k = 0; k < kCombDt; ++k) v0[u][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (!fill && pl.nsplit > 0) {   // (no split at all when every memory cell is masked: the read-out is 0)
+  if (!fill && pl.nsplit > 0 && !(RMNET_COMB_ABL & 8)) {   // (no split at all when every memory cell is masked: the read-out is 0)
 #pragma unroll
     for (int u = 0; u < kE; ++u)
 #pragma unroll
@@ -473,8 +476,8 @@ __global__ __launch_bounds__(kThreads, 6) void mr_combine(const KArgs a, int nqt
 #pragma unroll 8
     for (int dd = sl; dd < kCombCh; dd += 4) {
       const int d = d0 + dd;
-      out[(size_t)d * a.hw] = Tm[dd];
-      out[(size_t)(kDo + d) * a.hw] = qv[(size_t)d * a.hw] * 0.0f;   // q_val * box (:358), x*0 semantics
+      if (!(RMNET_COMB_ABL & 2)) out[(size_t)d * a.hw] = Tm[dd];
+      if (!(RMNET_COMB_ABL & 1)) out[(size_t)(kDo + d) * a.hw] = qv[(size_t)d * a.hw] * 0.0f;   // q_val * box (:358), x*0 semantics
     }
     return;
   }
@@ -569,9 +572,9 @@ __global__ __launch_bounds__(kThreads, 6) void mr_combine(const KArgs a, int nqt
 #pragma unroll 8
     for (int dd = sl; dd < kCombCh; dd += 4) {
       const int d = d0 + dd;
-      const float x = qvo[(size_t)d * a.hw + cell];
-      outo[(size_t)d * a.hw + cell] = inside ? Tt[dd][q] : Tm[dd];
-      outo[(size_t)(kDo + d) * a.hw + cell] = inside ? x : x * 0.0f;   // q_val * box (:358), x*0 semantics
+      const float x = (RMNET_COMB_ABL & 1) ? 0.0f : qvo[(size_t)d * a.hw + cell];
+      if (!(RMNET_COMB_ABL & 2)) outo[(size_t)d * a.hw + cell] = inside ? Tt[dd][q] : Tm[dd];
+      if (!(RMNET_COMB_ABL & 1)) outo[(size_t)(kDo + d) * a.hw + cell] = inside ? x : x * 0.0f;   // q_val * box (:358), x*0 semantics
     }
   }
 }

@@ -687,3 +687,28 @@ def test_region_map_of_the_warped_mask_is_bit_exact(B, K, H, W, amp):
     assert torch.equal(bb2, bb0)
     with pytest.raises(RuntimeError):
         ops.region_map(m, flow=f[:, :1].contiguous())
+
+
+def test_inference_harness_single_rank(oracle_mod):
+    """rmnet_amd.inference.segment_video / segment_videos (core/inference.py:49-63 without the file
+    output): flows from TinyFlowNet, device-resident frame loop, argmax labels -- equal to running the
+    two networks by hand; without a process group the 'gather' is the identity."""
+    from rmnet_amd import inference, networks
+    from rmnet_amd.synthetic import synthetic_clip
+    from rmnet_amd.tiny_flownet import TinyFlowNet
+    prod, _ = _nets(oracle_mod)
+    tfn = networks.procedural_init_(TinyFlowNet(None)).to(dev()).eval()
+    videos = []
+    for seed, n in ((3, 3), (4, 4)):
+        frames, masks, _, n_objects = synthetic_clip(n, 3, 96, 160, seed=seed, size=1.3)
+        videos.append({'frames': frames[0], 'masks': masks[0], 'n_objects': int(n_objects[0, 0])})
+    with torch.no_grad():
+        got = inference.segment_videos(videos, lambda v: inference.segment_video(prod, tfn, v, memorize_every=2))
+        for i, v in enumerate(videos):
+            fr = v['frames'].unsqueeze(0).to(dev())
+            n_obj = torch.full((1, fr.shape[1]), v['n_objects'], dtype=torch.long)
+            est = prod(fr, v['masks'].unsqueeze(0), tfn(fr), n_obj, 2)
+            want = est[0].argmax(1).to(torch.uint8)
+            assert got[i].dtype == torch.uint8 and got[i].shape == want.shape
+            assert (got[i] == want).float().mean() > 0.999
+    assert inference.video_costs(videos) == [3 * videos[0]['n_objects'], 4 * videos[1]['n_objects']]

@@ -116,3 +116,57 @@ def test_device_side_jaccard_matches_the_reference_definition(oracle_mod):
             assert abs(j[t, o - 1] - oracle_mod.iou(pred[t] == o, gt[t] == o)) < 1e-12
     assert j[2, 1] == 1.0
     assert abs(float(metrics.mean_jaccard(torch.from_numpy(pred), torch.from_numpy(gt), n)) - j[1:-1].mean()) < 1e-12
+
+
+def _shard_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from rmnet_amd import inference
+    g = torch.Generator().manual_seed(0)
+    videos = []
+    for v, (n, no) in enumerate([(5, 1), (9, 2), (3, 1), (7, 3), (4, 1)]):
+        labels = torch.randint(0, no + 1, (n, 6, 8), generator=g, dtype=torch.uint8)
+        videos.append({'frames': torch.zeros(n, 3, 6, 8), 'n_objects': no, 'labels': labels, 'id': v})
+    seen = []
+
+    def stub(video):                       # "prediction" = ground truth with object 1 erased on frame 1
+        seen.append(video['id'])
+        out = video['labels'].clone()
+        out[1][out[1] == 1] = 0
+        return out
+    maps = inference.segment_videos(videos, stub)
+    score = inference.evaluate_videos(videos, stub)
+    q.put((rank, sorted(seen), {k: v.clone() for k, v in maps.items()}, score))
+    dist.destroy_process_group()
+
+
+def test_sharded_video_inference_two_ranks_gloo():
+    """rmnet_amd.inference over 2 gloo ranks: every clip runs on exactly one rank, rank 0 receives all
+    label maps unchanged, and the all-reduced J equals the single-process value."""
+    import torch.multiprocessing as mp
+    from rmnet_amd import inference
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, seen0, maps0, j0), (r1, seen1, maps1, j1) = out
+    assert sorted(set(seen0) | set(seen1)) == [0, 1, 2, 3, 4] and not (set(seen0) & set(seen1))
+    assert sorted(maps0) == [0, 1, 2, 3, 4] and maps1 == {}
+    g = torch.Generator().manual_seed(0)
+    want_j_num = want_j_den = 0.0
+    from rmnet_amd import metrics
+    for v, (n, no) in enumerate([(5, 1), (9, 2), (3, 1), (7, 3), (4, 1)]):
+        labels = torch.randint(0, no + 1, (n, 6, 8), generator=g, dtype=torch.uint8)
+        pred = labels.clone()
+        pred[1][pred[1] == 1] = 0
+        assert torch.equal(maps0[v], pred)
+        j = metrics.jaccard_per_object(pred.long(), labels.long(), no)[1:-1]
+        want_j_num += float(j.sum()); want_j_den += j.numel()
+    assert abs(j0 - want_j_num / want_j_den) < 1e-12 and abs(j1 - j0) < 1e-12
