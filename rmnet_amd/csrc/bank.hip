@@ -23,14 +23,15 @@
 //
 // bk_append : one launch per memorised frame.  Reads k4/v4 (fp32, the reference's NCHW layout) once,
 //             compacts to the box, splits, transposes K through LDS, permutes V, writes the slot.
-// bk_main   : the read.  Workgroup = 12 waves = 64 compacted queries x one split of the tile list.
+// bk_main   : the read.  Workgroup = 12 waves = 64 compacted queries x one split of the tile list
+//             (the splits of all objects of a launch are planned together on the device).
 //             4 producer waves compute S for 16 queries each (v_mfma_f32_16x16x32_f16, K tile shared
-//             through swizzled LDS, filled by LDS-DMA), do the online soft-max in registers (a
-//             query's row lives in 4 lanes x 8 registers), split P to fp16 hi/lo in the MFMA
-//             B-fragment layout and publish the fragments in LDS; 8 consumer waves accumulate
-//             O += V P for 64 value channels x all 64 queries each, with the V A-fragments loaded
-//             straight from the bank into registers (16 B / lane, no LDS, no transpose) two tiles
-//             ahead.  ONE barrier per 32-cell tile.
+//             through a swizzled LDS ring), do the online soft-max in registers (a query's row
+//             lives in 4 lanes x 8 registers), split P to fp16 hi/lo in the MFMA B-fragment layout
+//             and publish the fragments in LDS; 8 consumer waves accumulate O += V P for 64 value
+//             channels x all 64 queries each, with the V A-fragments loaded straight from the bank
+//             into registers (16 B / lane, no LDS, no transpose) one tile ahead, and feed the K
+//             ring.  ONE barrier per 32-cell tile.
 // bk_combine: (memory_read.hip's mr_combine, shared) merges the splits, adds the closed-form term
 //             for the masked memory cells, scatters to query cells, appends q_val * box.
 #include "common.h"
@@ -237,8 +238,9 @@ constexpr int kRThreads = 64 * (kProducers + kConsumers);  // 768 = 12 waves = 3
 //               tile), online soft-max in registers, P -> fp16 hi/lo B-fragments -> LDS; the MFMAs
 //               of tile n+2 are interleaved with the soft-max VALU chain of tile n+1.
 //   waves 4-11 ("consumers"): O += V P for 64 value channels x 64 queries each (48 MFMAs per tile),
-//               V A-fragments straight from the bank into registers two tiles ahead; they also
-//               move the K tiles bank -> registers -> swizzled LDS ring (they have the slack).
+//               V A-fragments straight from the bank into registers, each channel tile refilled
+//               with the next tile right after its MFMAs; they also move the K tiles
+//               bank -> registers -> swizzled LDS ring (they have the slack).
 //   Wave i, i+4 and i+8 share a SIMD: the matrix pipe of every SIMD sees 24 + 2 x 48 = 120 MFMAs per
 //   tile.  The producer's serial chain (LDS fragment reads -> MFMAs -> soft-max VALU -> LDS publish)
 //   is shorter than that and runs one tile AHEAD of the PV, so the consumers never wait for it.
