@@ -343,14 +343,13 @@ __global__ __launch_bounds__(kThreads, 1) void mr_main(const KArgs a) {
   }
 }
 
-#ifndef RMNET_COMB_CH
-#define RMNET_COMB_CH 16
-#endif
 #ifndef RMNET_COMB_ABL
 #define RMNET_COMB_ABL 0   // experiments: 1 no q_val half, 2 no mem-half stores, 4 no fill blocks, 8 no partial loads
 #endif
-constexpr int kCombCh = RMNET_COMB_CH;  // read-out channels (and as many q_val channels) per combine block
-constexpr int kCombDt = kCombCh / 16;    // = channel tiles (fragments) per query tile and split
+// Read-out channels (and as many q_val channels) per combine block: 16 for one or two objects (more,
+// smaller workgroups: a launch is one latency chain deep), 32 beyond (fewer chains per byte moved).
+// Measured at 480p/T=5: 1 object 20.0 vs 22.1 us, 8 objects 39.2 vs 33.1 us.
+inline int comb_channels(int no) { return no <= 2 ? 16 : 32; }
 
 // Merge the per-split partials (fragment-ordered blocks, common.h).
 // grid = (nqt_max + cell tiles, kDo / kCombCh, no).  The plan comes from the 32-byte record the read
@@ -368,8 +367,9 @@ constexpr int kCombDt = kCombCh / 16;    // = channel tiles (fragments) per quer
 //        box only (mean-slot vector, q_val * 0).  Skipped when nothing is masked.
 // The bank kernel keeps its running reference in the log2 domain (2^x soft-max), mr_main in the
 // natural one; a.bank_area tells which.
-template <bool REGIONAL>
-__global__ __launch_bounds__(kThreads, 6) void mr_combine(const KArgs a, int nqt_max) {   // <= 80 VGPRs: 6 workgroups' worth of waves per SIMD hide this kernel's latency chains
+template <bool REGIONAL, int kCombCh>
+__global__ __launch_bounds__(kThreads, 6) void mr_combine(const KArgs a, int nqt_max) {
+  constexpr int kCombDt = kCombCh / 16;    // = channel tiles (fragments) per query tile and split   // <= 80 VGPRs: 6 workgroups' worth of waves per SIMD hide this kernel's latency chains
   __shared__ float Wt[kMaxSplits][kQT];
   __shared__ float Wm[kMaxSplits];
   __shared__ float red[4][kQT];
@@ -681,6 +681,16 @@ inline bool fast_shape(int De, int Do, int T, int flags) {
   return De == kDe && Do == kDo && T <= kMaxT && !(flags & RMNET_MR_FORCE_GENERIC);
 }
 
+inline void launch_combine(bool regional, int cch, dim3 grid, hipStream_t st, const KArgs& a, int nqt_max) {
+  if (regional) {
+    if (cch == 16) hipLaunchKernelGGL((mr_combine<true, 16>), grid, dim3(kThreads), 0, st, a, nqt_max);
+    else hipLaunchKernelGGL((mr_combine<true, 32>), grid, dim3(kThreads), 0, st, a, nqt_max);
+  } else {
+    if (cch == 16) hipLaunchKernelGGL((mr_combine<false, 16>), grid, dim3(kThreads), 0, st, a, nqt_max);
+    else hipLaunchKernelGGL((mr_combine<false, 32>), grid, dim3(kThreads), 0, st, a, nqt_max);
+  }
+}
+
 inline int slots_for(int no, int hw) {
   const int nqt_max = (hw + 1 + kQT - 1) / kQT;
   const int per_obj = (kTargetSlots + no - 1) / no;
@@ -733,7 +743,8 @@ int launch_memory_read(const MemReadArgs& m, hipStream_t st) {
                                            align256((size_t)m.no * a.slots * 2 * kQT * 4));
     const int nqt_max = (int)((hw + 1 + kQT - 1) / kQT);
     dim3 g1(a.slots, m.no);
-    dim3 g2((unsigned)(nqt_max + (regional ? (hw + kQT - 1) / kQT : 0)), kDo / kCombCh, m.no);
+    const int cch = comb_channels(m.no);
+    dim3 g2((unsigned)(nqt_max + (regional ? (hw + kQT - 1) / kQT : 0)), kDo / cch, m.no);
     if (m.ev_start && hipEventRecord(m.ev_start, st) != hipSuccess) return RMNET_E_LAUNCH;
     if (regional)
       hipLaunchKernelGGL(mr_main<true>, g1, dim3(kThreads), 0, st, a);
@@ -742,9 +753,9 @@ int launch_memory_read(const MemReadArgs& m, hipStream_t st) {
     if (int e = check_launch()) return e;
     if (m.ev_mid && hipEventRecord(m.ev_mid, st) != hipSuccess) return RMNET_E_LAUNCH;
     if (regional)
-      hipLaunchKernelGGL(mr_combine<true>, g2, dim3(kThreads), 0, st, a, nqt_max);
+      launch_combine(true, cch, g2, st, a, nqt_max);
     else
-      hipLaunchKernelGGL(mr_combine<false>, g2, dim3(kThreads), 0, st, a, nqt_max);
+      launch_combine(false, cch, g2, st, a, nqt_max);
     if (int e = check_launch()) return e;
     if (m.ev_end && hipEventRecord(m.ev_end, st) != hipSuccess) return RMNET_E_LAUNCH;
     if (!m.p_out) return RMNET_OK;
@@ -807,11 +818,12 @@ int launch_bank_read(BankReadArgs& m, hipStream_t st) {
   a.ws_o = m.ws_o; a.ws_ml = m.ws_ml; a.ws_plan = m.ws_plan;
   const int nqt_max = (hw + 1 + kQT - 1) / kQT;
   const bool qreg = m.qry_rects != nullptr;
-  dim3 g2((unsigned)(nqt_max + (qreg ? (hw + kQT - 1) / kQT : 0)), kDo / kCombCh, m.no);
+  const int cch = comb_channels(m.no);
+  dim3 g2((unsigned)(nqt_max + (qreg ? (hw + kQT - 1) / kQT : 0)), kDo / cch, m.no);
   if (qreg)
-    hipLaunchKernelGGL(mr_combine<true>, g2, dim3(kThreads), 0, st, a, nqt_max);
+    launch_combine(true, cch, g2, st, a, nqt_max);
   else
-    hipLaunchKernelGGL(mr_combine<false>, g2, dim3(kThreads), 0, st, a, nqt_max);
+    launch_combine(false, cch, g2, st, a, nqt_max);
   if (int e = check_launch()) return e;
   if (m.ev_end && hipEventRecord(m.ev_end, st) != hipSuccess) return RMNET_E_LAUNCH;
   return RMNET_OK;
