@@ -22,7 +22,8 @@
 //   at 16x/3 the rate of the fp32 MFMA.  Bytes per element are the same as fp32 (2 + 2).
 //
 // bk_append : one launch per memorised frame.  Reads k4/v4 (fp32, the reference's NCHW layout) once,
-//             compacts to the box, splits, transposes K through LDS, permutes V, writes the slot.
+//             compacts to the box, splits, transposes 128-channel chunks through LDS (K to
+//             cell-major rows, V to fragment order), writes the slot.
 // bk_main   : the read.  Workgroup = 12 waves = 64 compacted queries x one split of the tile list
 //             (the splits of all objects of a launch are planned together on the device).
 //             4 producer waves compute S for 16 queries each (v_mfma_f32_16x16x32_f16, K tile shared
@@ -130,67 +131,68 @@ __global__ __launch_bounds__(kThreads) void bk_append(BankView b, int slot,
     cell = (rc.cy0 + ry) * b.w + rc.cx0 + (n - ry * rw);
   }
   const size_t so = (size_t)o * b.Tcap + slot;
-  // keys: gather [c][cell] -> LDS [p][c] -> split -> [n][c]
-  const float* kb = k4 + (size_t)o * kDe * b.hw + cell;
+  // grid.z = 1 + kDo / kDe: slice 0 converts the keys, slices 1.. one 128-channel chunk of the values
+  // each (five short dependency chains instead of one long one: a launch has < 1 workgroup per CU)
+  if (blockIdx.z == 0) {
+    // keys: gather [c][cell] -> LDS [p][c] -> split -> [n][c]
+    const float* kb = k4 + (size_t)o * kDe * b.hw + cell;
 #pragma unroll
-  for (int i = 0; i < kDe / 8; ++i) {
-    const int c = rg + 8 * i;
-    tile[p][c] = valid ? kb[(size_t)c * b.hw] : 0.0f;
-  }
-  __syncthreads();
-  {
-    const int row = tid >> 3, c0 = (tid & 7) * 16;
-    half8 h0, h1, l0, l1;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      _Float16 hi, lo;
-      split_f16(tile[row][c0 + e], hi, lo);
-      h0[e] = hi; l0[e] = lo;
-      split_f16(tile[row][c0 + 8 + e], hi, lo);
-      h1[e] = hi; l1[e] = lo;
+    for (int i = 0; i < kDe / 8; ++i) {
+      const int c = rg + 8 * i;
+      tile[p][c] = valid ? kb[(size_t)c * b.hw] : 0.0f;
     }
-    const size_t off = ((so * b.hwp + (size_t)u * kJT + row) * kDe + c0) * sizeof(_Float16);
-    *reinterpret_cast<half8*>(b.kh + off) = h0;
-    *reinterpret_cast<half8*>(b.kh + off + 16) = h1;
-    *reinterpret_cast<half8*>(b.kl + off) = l0;
-    *reinterpret_cast<half8*>(b.kl + off + 16) = l1;
-  }
-  // values: gather [d][cell] -> split -> fragment order [tile u][d/16][lane = d%16 + 16 g][8 cells].
-  // One thread builds one whole 16-byte fragment row (channel d, lane group gg): its 8 cells are the
-  // compact offsets {4gg..4gg+3, 16+4gg..16+4gg+3} (kperm), fetched with 8 scalar gathers, split, and
-  // written with ONE 16-byte store per plane; a wave covers 16 channels x 4 groups = 4 x 256 B runs.
-  {
-    const int gg = tid & 3;
-    int cells[8];
-    bool ok[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int j = 4 * gg + (e & 3) + 16 * (e >> 2);
-      const int nn = u * kJT + j;
-      ok[e] = nn < area;
-      int cc = 0;
-      if (ok[e]) {
-        const int rw = rc.width(), ry = nn / rw;
-        cc = (rc.cy0 + ry) * b.w + rc.cx0 + (nn - ry * rw);
-      }
-      cells[e] = cc;
-    }
-    const float* vb = v4 + (size_t)o * kDo * b.hw;
-    const size_t vbase = (so * (b.hwp / kJT) + u) * (size_t)(kDo * kJT) * sizeof(_Float16);
-#pragma unroll 2
-    for (int i = 0; i < kDo / 64; ++i) {
-      const int d = (tid >> 2) + 64 * i;
-      half8 hi8, lo8;
+    __syncthreads();
+    {
+      const int row = tid >> 3, c0 = (tid & 7) * 16;
+      half8 h0, h1, l0, l1;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float x = ok[e] ? vb[(size_t)d * b.hw + cells[e]] : 0.0f;
         _Float16 hi, lo;
-        split_f16(x, hi, lo);
-        hi8[e] = hi; lo8[e] = lo;
+        split_f16(tile[row][c0 + e], hi, lo);
+        h0[e] = hi; l0[e] = lo;
+        split_f16(tile[row][c0 + 8 + e], hi, lo);
+        h1[e] = hi; l1[e] = lo;
       }
-      const size_t off = vbase + (size_t)(((d >> 4) * 64) + (d & 15) + 16 * gg) * 16;
-      *reinterpret_cast<half8*>(b.vh + off) = hi8;
-      *reinterpret_cast<half8*>(b.vl + off) = lo8;
+      const size_t off = ((so * b.hwp + (size_t)u * kJT + row) * kDe + c0) * sizeof(_Float16);
+      *reinterpret_cast<half8*>(b.kh + off) = h0;
+      *reinterpret_cast<half8*>(b.kh + off + 16) = h1;
+      *reinterpret_cast<half8*>(b.kl + off) = l0;
+      *reinterpret_cast<half8*>(b.kl + off + 16) = l1;
+    }
+    return;
+  }
+  // values: 128 channels at a time through the same LDS tile (coalesced gather along cells, like the
+  // keys), then fragment order [tile u][d/16][lane = d%16 + 16 g][8 cells]: one thread builds one
+  // whole 16-byte fragment row (channel d, lane group gg) -- its 8 cells are the compact offsets
+  // {4gg..4gg+3, 16+4gg..16+4gg+3} (kperm) -- from 8 LDS reads and writes it with ONE
+  // 16-byte store per plane; a wave covers 16 channels x 4 groups = 4 x 256 B runs.
+  {
+    const float* vb = v4 + (size_t)o * kDo * b.hw + cell;
+    const size_t vbase = (so * (b.hwp / kJT) + u) * (size_t)(kDo * kJT) * sizeof(_Float16);
+    const int gg = tid & 3;
+    {
+      const int c0 = ((int)blockIdx.z - 1) * kDe;
+#pragma unroll
+      for (int i = 0; i < kDe / 8; ++i) {
+        const int c = rg + 8 * i;
+        tile[p][c] = valid ? vb[(size_t)(c0 + c) * b.hw] : 0.0f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < kDe / 64; ++i) {
+        const int dl = (tid >> 2) + 64 * i, d = c0 + dl;
+        half8 hi8, lo8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int j = 4 * gg + (e & 3) + 16 * (e >> 2);
+          _Float16 hi, lo;
+          split_f16(tile[j][dl], hi, lo);
+          hi8[e] = hi; lo8[e] = lo;
+        }
+        const size_t off = vbase + (size_t)(((d >> 4) * 64) + (d & 15) + 16 * gg) * 16;
+        *reinterpret_cast<half8*>(b.vh + off) = hi8;
+        *reinterpret_cast<half8*>(b.vl + off) = lo8;
+      }
     }
   }
 }
@@ -784,7 +786,7 @@ int launch_bank_append(void* bank, int no, int Tcap, int h, int w, int slot, con
     return RMNET_E_INVALID_ARG;
   if (no > 65535 || Tcap > kMaxT) return RMNET_E_UNSUPPORTED;
   const BankView b = bank_view(bank, no, Tcap, h, w);
-  hipLaunchKernelGGL(bk_append, dim3(b.hwp / kJT, no), dim3(kThreads), 0, st, b, slot, k4, v4, rects);
+  hipLaunchKernelGGL(bk_append, dim3(b.hwp / kJT, no, 1 + kDo / kDe), dim3(kThreads), 0, st, b, slot, k4, v4, rects);
   return check_launch();
 }
 
