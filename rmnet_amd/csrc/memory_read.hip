@@ -369,7 +369,7 @@ inline int comb_channels(int no) { return no <= 2 ? 16 : 32; }
 // natural one; a.bank_area tells which.
 template <bool REGIONAL, int kCombCh>
 __global__ __launch_bounds__(kThreads, 6) void mr_combine(const KArgs a, int nqt_max) {
-  constexpr int kCombDt = kCombCh / 16;    // = channel tiles (fragments) per query tile and split   // <= 80 VGPRs: 6 workgroups' worth of waves per SIMD hide this kernel's latency chains
+  constexpr int kCombDt = kCombCh / 16;    // = channel tiles (fragments) per query tile and split
   __shared__ float Wt[kMaxSplits][kQT];
   __shared__ float Wm[kMaxSplits];
   __shared__ float red[4][kQT];
@@ -427,46 +427,94 @@ __global__ __launch_bounds__(kThreads, 6) void mr_combine(const KArgs a, int nqt
         v0[u][k] = *reinterpret_cast<const f32x4*>(psrc + (size_t)min(u, pl.nsplit - 1) * sstride + (size_t)k * 1024);
   }
 
-  // ---- mean-slot vector (one wave): weights of compacted query Mq, then its 64 channels
-  if (masked) {
-    const int qtm = pl.Mq >> 6, mq = pl.Mq & 63;
-    if (tid < RMNET_WAVE) {
-      const float* e = ml + ((size_t)(tid * pl.nqt + qtm) * 2) * kQT;
-      const bool on = tid < pl.nsplit;
-      const float ms = on ? e[mq] : -INFINITY;
-      float mtot = ms;
+  // Everything the weights need is requested before the first barrier: this tile's (m, l) pairs of up
+  // to 16 splits in registers (the rest, rare, is re-read in both passes below), the mean slot's
+  // pairs in wave 0.  Three barriers in all; the mean-slot channels are fetched while the weights
+  // are being formed.
+  constexpr int kMl = 4;                  // register-held splits per thread (x 4 thread groups = 16)
+  constexpr int kTmParts = kThreads / kCombCh;
+  __shared__ float red2[4][kQT];
+  __shared__ float tp[kTmParts][kCombCh];
+  const int qtm = pl.Mq >> 6, mq = pl.Mq & 63;
+  float m_r[kMl], l_r[kMl];
+  if (!fill) {
 #pragma unroll
-      for (int d = 32; d > 0; d >>= 1) mtot = fmaxf(mtot, __shfl_xor(mtot, d));
-      if (n_out > 0.0f) mtot = fmaxf(mtot, 0.0f);
-      const float wgt = on ? ex(ms - mtot) : 0.0f;
-      float ltot = on ? e[kQT + mq] * wgt : 0.0f;
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) ltot += __shfl_xor(ltot, d);
-      if (n_out > 0.0f) ltot += n_out * ex(-mtot);
-      Wm[tid] = wgt / ltot;
+    for (int j = 0; j < kMl; ++j) {
+      const int sj = sl + 4 * j;
+      const float* e = ml + ((size_t)(min(sj, max(pl.nsplit - 1, 0)) * pl.nqt + qt) * 2) * kQT;
+      const bool on = sj < pl.nsplit;
+      m_r[j] = on ? e[qi] : -INFINITY;
+      l_r[j] = on ? e[kQT + qi] : 0.0f;
     }
-    __syncthreads();
-    {   // 256 threads = kCombCh channels x kTmParts interleaved subsets of the splits (loads independent)
-      constexpr int kTmParts = kThreads / kCombCh;
-      const int chn = tid % kCombCh, part = tid / kCombCh;
-      const float* __restrict__ src = wo + (size_t)qtm * kDo * kQT + partial_elem_offset(mq, d0 + chn);
-      float acc = 0.0f;
+  }
+  float mm = -INFINITY, lm = 0.0f;        // mean slot (wave 0, lane = split)
+  if (masked && tid < RMNET_WAVE && tid < pl.nsplit) {
+    const float* e = ml + ((size_t)(tid * pl.nqt + qtm) * 2) * kQT;
+    mm = e[mq];
+    lm = e[kQT + mq];
+  }
+
+  // ---- pass 1: row maxima; wave 0 also finishes the mean slot's weights (shuffles only)
+  if (!fill) {
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < kMl; ++j) mloc = fmaxf(mloc, m_r[j]);
+    for (int sj = sl + 4 * kMl; sj < pl.nsplit; sj += 4) mloc = fmaxf(mloc, ml[((size_t)(sj * pl.nqt + qt) * 2) * kQT + qi]);
+    red[sl][qi] = mloc;
+  }
+  if (masked && tid < RMNET_WAVE) {
+    float mtot = mm;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mtot = fmaxf(mtot, __shfl_xor(mtot, d));
+    if (n_out > 0.0f) mtot = fmaxf(mtot, 0.0f);
+    const float wgt = tid < pl.nsplit ? ex(mm - mtot) : 0.0f;
+    float ltot = lm * wgt;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) ltot += __shfl_xor(ltot, d);
+    if (n_out > 0.0f) ltot += n_out * ex(-mtot);
+    Wm[tid] = wgt / ltot;
+  }
+  __syncthreads();                                                         // barrier 1
+
+  // ---- mean-slot channels (requested now, summed after the weights) + pass 2: the weights
+  float tm_acc = 0.0f;
+  if (masked) {   // 256 threads = kCombCh channels x kTmParts interleaved subsets of the splits
+    const int chn = tid % kCombCh, part = tid / kCombCh;
+    const float* __restrict__ src = wo + (size_t)qtm * kDo * kQT + partial_elem_offset(mq, d0 + chn);
 #pragma unroll 4
-      for (int s = part; s < pl.nsplit; s += kTmParts) acc += Wm[s] * src[(size_t)s * sstride];
-      float* tp = &Tt[0][0];                         // (Tt is not in use yet)
-      tp[part * kCombCh + chn] = acc;
-      __syncthreads();
-      if (tid < kCombCh) {
-        float t = 0.0f;
+    for (int s2 = part; s2 < pl.nsplit; s2 += kTmParts) tm_acc += Wm[s2] * src[(size_t)s2 * sstride];
+  }
+  if (!fill) {
+    float mtot = fmaxf(fmaxf(red[0][qi], red[1][qi]), fmaxf(red[2][qi], red[3][qi]));
+    if (n_out > 0.0f) mtot = fmaxf(mtot, 0.0f);        // the N_out masked memory cells have S = 0
+    float lloc = 0.0f;
 #pragma unroll
-        for (int p = 0; p < kTmParts; ++p) t += tp[p * kCombCh + tid];
-        Tm[tid] = t;
-      }
+    for (int j = 0; j < kMl; ++j) {
+      const int sj = sl + 4 * j;
+      const float wgt = ex(m_r[j] - mtot);              // (-inf for a split that does not exist: 0)
+      if (sj < kMaxSplits) Wt[sj][qi] = wgt;
+      lloc += l_r[j] * wgt;
     }
-    __syncthreads();
+    for (int sj = sl + 4 * kMl; sj < pl.nsplit; sj += 4) {
+      const float* e = ml + ((size_t)(sj * pl.nqt + qt) * 2) * kQT;
+      const float wgt = ex(e[qi] - mtot);
+      Wt[sj][qi] = wgt;
+      lloc += e[kQT + qi] * wgt;
+    }
+    // (the closed-form term of the N_out masked memory cells rides in group 0's partial sum)
+    red2[sl][qi] = lloc + (sl == 0 && n_out > 0.0f ? n_out * ex(-mtot) : 0.0f);
+  }
+  if (masked) tp[tid / kCombCh][tid % kCombCh] = tm_acc;
+  __syncthreads();                                                         // barrier 2
+  if (masked && tid < kCombCh) {
+    float t = 0.0f;
+#pragma unroll
+    for (int pp = 0; pp < kTmParts; ++pp) t += tp[pp][tid];
+    Tm[tid] = t;
   }
 
   if (fill) {
+    __syncthreads();                                                       // (Tm visible)
     const int cell = fc0 + qi;
     if (cell >= a.hw) return;
     const int cy = cell / a.w;
@@ -482,41 +530,16 @@ __global__ __launch_bounds__(kThreads, 6) void mr_combine(const KArgs a, int nqt
     return;
   }
 
-  // ---- split weights for the 64 queries of tile qt
-  float mloc = -INFINITY;
-#pragma unroll 4
-  for (int s = sl; s < pl.nsplit; s += 4) mloc = fmaxf(mloc, ml[((size_t)(s * pl.nqt + qt) * 2) * kQT + qi]);
-  red[sl][qi] = mloc;
-  __syncthreads();
-  float mtot = fmaxf(fmaxf(red[0][qi], red[1][qi]), fmaxf(red[2][qi], red[3][qi]));
-  if (n_out > 0.0f) mtot = fmaxf(mtot, 0.0f);        // the N_out masked memory cells have S = 0
-  __syncthreads();
-  float lloc = 0.0f;
-#pragma unroll 4
-  for (int s = sl; s < pl.nsplit; s += 4) {
-    const float* e = ml + ((size_t)(s * pl.nqt + qt) * 2) * kQT;
-    const float wgt = ex(e[qi] - mtot);
-    Wt[s][qi] = wgt;
-    lloc += e[kQT + qi] * wgt;
-  }
-  red[sl][qi] = lloc;
-  __syncthreads();
-  float ltot = red[0][qi] + red[1][qi] + red[2][qi] + red[3][qi];
-  if (n_out > 0.0f) ltot += n_out * ex(-mtot);
-  const float inv = 1.0f / ltot;
-  for (int s = sl; s < pl.nsplit; s += 4) Wt[s][qi] *= inv;
-  for (int s = pl.nsplit + sl; s < kE; s += 4) Wt[s][qi] = 0.0f;   // clamped duplicates of the early batch
-  __syncthreads();
-
   {  // accumulate: thread = (query tile it = sl, lane qi) of the channel tiles of this block
     const int q = sl * 16 + (qi & 15), gg = qi >> 4;
+    const float inv = 1.0f / (red2[0][q] + red2[1][q] + red2[2][q] + red2[3][q]);
     f32x4 acc[kCombDt];
 #pragma unroll
     for (int k = 0; k < kCombDt; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* __restrict__ src = psrc;
 #pragma unroll
     for (int u = 0; u < kE; ++u) {
-      const float wgt = Wt[u][q];
+      const float wgt = u < pl.nsplit ? Wt[u][q] : 0.0f;   // (clamped duplicates of the early batch)
 #pragma unroll
       for (int k = 0; k < kCombDt; ++k) acc[k] += wgt * v0[u][k];
     }
@@ -544,9 +567,9 @@ __global__ __launch_bounds__(kThreads, 6) void mr_combine(const KArgs a, int nqt
 #pragma unroll
     for (int k = 0; k < kCombDt; ++k)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Tt[k * 16 + 4 * gg + r][q] = acc[k][r];
+      for (int r = 0; r < 4; ++r) Tt[k * 16 + 4 * gg + r][q] = acc[k][r] * inv;
   }
-  __syncthreads();
+  __syncthreads();                                                         // barrier 3
 
   // ---- write-out: the contiguous cell range this tile owns
   float* __restrict__ outo = a.out + (size_t)o * 2 * kDo * a.hw;
