@@ -201,7 +201,7 @@ class RMNet(nn.Module):
         (frame,), pad = pad_divide_by([frame], 16, frame.shape[2:])
         r4, r3, r2, _, _ = self.encoder_query(frame)
         k4, v4 = self.kv_query(r4)
-        if frame.shape[0] == 1 and len(batch_of_obj) == 1:
+        if all(int(n) == 1 for n in n_objects):     # one object per clip: object i IS clip i, no expansion copies
             k4e, v4e, r3e, r2e = k4, v4, r3, r2
         else:
             k4e, v4e = k4.index_select(0, batch_of_obj), v4.index_select(0, batch_of_obj)
