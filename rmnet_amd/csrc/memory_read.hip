@@ -368,7 +368,7 @@ inline int comb_channels(int no) { return no <= 2 ? 16 : 32; }
 // The bank kernel keeps its running reference in the log2 domain (2^x soft-max), mr_main in the
 // natural one; a.bank_area tells which.
 template <bool REGIONAL, int kCombCh>
-__global__ __launch_bounds__(kThreads, 6) void mr_combine(const KArgs a, int nqt_max) {
+__global__ __launch_bounds__(kThreads, kCombCh == 16 ? 6 : 5) void mr_combine(const KArgs a, int nqt_max) {   // (register cap: many resident workgroups hide the latency chain; LDS allows 5 at 32 channels)
   constexpr int kCombDt = kCombCh / 16;    // = channel tiles (fragments) per query tile and split
   __shared__ float Wt[kMaxSplits][kQT];
   __shared__ float Wm[kMaxSplits];
