@@ -253,7 +253,9 @@ def main():
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'mr_main_hbm_traffic.json')   # from a separate --pmc pass
     if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
+        tj = json.load(open(tpath))
+        if int(tj.get('algorithmic_bytes_per_launch', -1)) == int(abytes):   # measured for this very workload
+            traffic = tj.get('hbm_bytes_per_launch')
 
     if rank == 0:
         line = {
