@@ -461,8 +461,14 @@ def _clip_with_late_object(N, H, W, seed):
     return frames, masks, flows, n_objects
 
 
-def test_rmnet_new_object_and_batch_of_clips(oracle_mod):
+@pytest.mark.parametrize('fused', [False, True])
+def test_rmnet_new_object_and_batch_of_clips(fused, oracle_mod):
+    """Two clips batched, one gaining an object mid-clip (models/rmnet.py:436-448): the module graph
+    and the fused path (epilogue kernels, warp-fused boxes, one-kernel decoder tail -- whose soft-max
+    must be bypassed on the frames where the logits are edited) against the CPU path."""
     prod, ref = _nets(oracle_mod)
+    if fused:
+        prod.fuse_epilogues()
     f1, m1, fl1, n1 = _clip_with_late_object(5, 96, 160, seed=11)
     f2, m2, fl2, n2 = _clip_with_late_object(5, 96, 160, seed=12)
     n2 = torch.full_like(n2, 2)
