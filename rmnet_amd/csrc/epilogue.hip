@@ -21,7 +21,7 @@ constexpr int kThreads = 256;
 constexpr int kUnroll = 4;
 
 template <bool VEC4, bool RES>
-__global__ __launch_bounds__(kThreads) void channel_affine(const float* __restrict__ x,
+__global__ __launch_bounds__(kThreads) void channel_affine(const float* x,   // (may alias out: no restrict)
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
                                                            const float* res,
