@@ -51,6 +51,11 @@ def test_invalid_arguments_are_reported_not_launched():
                                     None, 0, None) == -1
     assert lib.rmnet_memory_read_f32(None, None, None, None, 1, 128, 512, 1, 4, 4, 0, 0, 0, 0, None, None,
                                      None, None, 0, None, 0, None) == -1
+    assert lib.rmnet_channel_affine_f32(None, None, None, None, None, None, 1, 1, 4, 16, None, None) == -1
+    assert lib.rmnet_upsample2x_add_f32(None, None, 1, 4, 8, 8, None, None) == -1
+    assert lib.rmnet_soft_aggregate_f32(None, None, 1, 2, 16, 16, 0, 0, 16, 16, None, None, None) == -1
+    assert lib.rmnet_region_map_warped_f32(None, None, 1, 2, 8, 8, 0.5, 10, 64, None, None, None, 0, 0, 16, 1, 1,
+                                           None, None, 0, None) == -1
 
 
 def test_ops_reject_cpu_tensors_like_the_reference():
@@ -63,3 +68,11 @@ def test_ops_reject_cpu_tensors_like_the_reference():
     with pytest.raises(RuntimeError, match='CUDA'):
         ops.memory_read(torch.zeros(1, 128, 1, 2, 2), torch.zeros(1, 512, 1, 2, 2),
                         torch.zeros(1, 128, 2, 2), torch.zeros(1, 512, 2, 2))
+    with pytest.raises(RuntimeError, match='CUDA'):
+        ops.channel_affine(torch.zeros(1, 4, 2, 2), torch.ones(4), torch.zeros(4))
+    with pytest.raises(RuntimeError, match='CUDA'):
+        ops.upsample2x_add(torch.zeros(1, 4, 2, 2))
+    with pytest.raises(RuntimeError, match='CUDA'):
+        ops.soft_aggregate(torch.zeros(1, 2, 16, 16), torch.zeros(2, dtype=torch.int32), 2, (0, 0, 0, 0))
+    with pytest.raises(RuntimeError, match='CUDA'):
+        ops.region_map(torch.zeros(1, 2, 8, 8), flow=torch.zeros(1, 2, 8, 8))
