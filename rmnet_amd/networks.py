@@ -142,8 +142,12 @@ class EncoderMemory(nn.Module):
         m = in_m.unsqueeze(1).float()
         o = in_o.unsqueeze(1).float()
         if getattr(self, '_fused', False) and in_f.is_cuda:
+            # conv1(f) + conv1_m(m) + conv1_o(o) is ONE 7x7 convolution over the 5 stacked input
+            # channels with the three weights stacked the same way: two convolutions and two
+            # full-resolution adds fewer, same sum up to fp32 summation order.
             from . import ops
-            t = self.conv1(in_f).add_(self.conv1_m(m)).add_(self.conv1_o(o))
+            c = self.conv1
+            t = F.conv2d(torch.cat((in_f, m, o), dim=1), self._w5, None, c.stride, c.padding)
             c1 = ops.channel_affine(t, self._s1, self._b1, relu=True, out=t)
         else:
             c1 = self.relu(self.bn1(self.conv1(in_f) + self.conv1_m(m) + self.conv1_o(o)))
@@ -363,6 +367,8 @@ def fuse_epilogues_(module, enable=True):
             sc, sh = _bn_scale_shift(m.bn1)
             put(m, '_s1', sc.contiguous())
             put(m, '_b1', sh.contiguous())
+            if isinstance(m, EncoderMemory):
+                put(m, '_w5', torch.cat((m.conv1.weight, m.conv1_m.weight, m.conv1_o.weight), dim=1).contiguous())
             m._fused = bool(enable)
         elif isinstance(m, (ResBlock, Refine)):
             m._fused = bool(enable)
