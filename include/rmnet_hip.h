@@ -169,6 +169,13 @@ int rmnet_channel_affine_f32(const float *x, const float *scale, const float *sh
                              const float *res, const float *res_scale, const float *res_shift,
                              int relu, long long N, int C, long long HW, float *out, void *stream);
 
+/* C1 glue: out = max_pool2d(relu(x * scale[c] + shift[c]), kernel 3, stride 2, padding 1), x [N,C,H,W] ->
+ * out [N,C,(H-1)/2+1,(W-1)/2+1] fp32 NCHW; scale / shift may be NULL.  Replaces bn1 -> relu -> maxpool of
+ * the ResNet-50 stems (torchvision layers used at models/rmnet.py:66-70, 96-98) without writing the
+ * full-resolution activation. */
+int rmnet_affine_relu_maxpool_f32(const float *x, const float *scale, const float *shift, long long N,
+                                  int C, int H, int W, float *out, void *stream);
+
 /* C1 glue: out = skip + bilinear_x2(x), x [N,C,h,w] -> out / skip [N,C,2h,2w] fp32 NCHW, with
  * torch's align_corners=False source-index rule.  skip may be NULL (plain upsample); out may be skip.
  * Replaces F.interpolate(pm, scale_factor=2, mode='bilinear') and the add of Refine.forward

@@ -143,6 +143,11 @@ int rmnet_region_map_warped_f32(const float* mask, const float* flow, int B, int
                                   static_cast<hipStream_t>(stream));
 }
 
+int rmnet_affine_relu_maxpool_f32(const float* x, const float* scale, const float* shift, long long N,
+                                  int C, int H, int W, float* out, void* stream) {
+  return launch_affine_relu_maxpool(x, scale, shift, N, C, H, W, out, static_cast<hipStream_t>(stream));
+}
+
 int rmnet_flow_affine_f32(const float* flow, const float* m1, const float* m2, int H, int W,
                           float* out, void* stream) {
   return launch_flow_affine(flow, m1, m2, H, W, out, static_cast<hipStream_t>(stream));

@@ -75,6 +75,8 @@ int launch_upsample2x_add(const float* x, const float* skip, long long N, int C,
 int launch_soft_aggregate(const float* dec, const int32_t* obj_begin, int B, int K, int Hp, int Wp,
                           int pad_l, int pad_t, int H, int W, float* logit, float* prob,
                           hipStream_t st);
+int launch_affine_relu_maxpool(const float* x, const float* scale, const float* shift, long long N,
+                               int C, int H, int W, float* out, hipStream_t st);
 int launch_flow_affine(const float* flow, const float* m1, const float* m2, int H, int W,
                        float* out, hipStream_t st);
 

@@ -195,6 +195,80 @@ __global__ __launch_bounds__(kThreads) void soft_aggregate(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// ResNet stem tail: relu(x * scale[c] + shift[c]) followed by MaxPool2d(3, stride 2, padding 1)
+// (torchvision resnet50's bn1 / relu / maxpool under models/rmnet.py:66-70, 96-98) in one pass: the
+// full-resolution activation (212 MB per encoder at eight 480p clips) is read once and never written.
+// Padding counts as -inf like torch's max_pool2d; a NaN in the window gives NaN.
+template <bool VEC4>
+__global__ __launch_bounds__(kThreads) void affine_relu_maxpool(const float* __restrict__ x,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift,
+                                                                int C, long long planes, int H, int W,
+                                                                int Ho, int Wo, float* __restrict__ out) {
+  const int per_row = VEC4 ? Wo >> 2 : Wo;          // VEC4: W = 2 Wo, Wo % 4 == 0, 16-byte aligned rows
+  const int items = Ho * per_row;
+  for (long long plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+    const int c = (int)(plane % C);
+    const float sc = scale ? scale[c] : 1.0f, sh = shift ? shift[c] : 0.0f;
+    const float* xp = x + (size_t)plane * H * W;
+    float* op = out + (size_t)plane * Ho * Wo;
+    auto act = [&](float v, bool& nan) {
+      v = v * sc + sh;
+      nan = nan || v != v;
+      return v < 0.0f ? 0.0f : v;
+    };
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < items; i += gridDim.x * kThreads) {
+      const int yo = i / per_row, xq = i - yo * per_row;
+      if (VEC4) {
+        // 4 outputs from the 9 input columns 8 xq - 1 .. 8 xq + 7 of 3 rows: two 16-byte loads and
+        // one scalar per row
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        bool nan[4] = {false, false, false, false};
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+          const int y = 2 * yo + dy;
+          if (y < 0 || y >= H) continue;
+          const float* row = xp + (size_t)y * W + 8 * xq;
+          const float4 a = *reinterpret_cast<const float4*>(row);
+          const float4 bq = *reinterpret_cast<const float4*>(row + 4);
+          const bool has_left = xq > 0;
+          const float left = has_left ? row[-1] : 0.0f;
+          const float v[9] = {left, a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+              if (j == 0 && dx == 0 && !has_left) continue;
+              const float t = act(v[2 * j + dx], nan[j]);
+              best[j] = t > best[j] ? t : best[j];
+            }
+        }
+        float4 o;
+        o.x = nan[0] ? __builtin_nanf("") : best[0]; o.y = nan[1] ? __builtin_nanf("") : best[1];
+        o.z = nan[2] ? __builtin_nanf("") : best[2]; o.w = nan[3] ? __builtin_nanf("") : best[3];
+        *reinterpret_cast<float4*>(op + (size_t)yo * Wo + 4 * xq) = o;
+      } else {
+        float best = -INFINITY;
+        bool nan = false;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+          const int y = 2 * yo + dy;
+#pragma unroll
+          for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = 2 * xq + dx;
+            if (y >= 0 && y < H && xx >= 0 && xx < W) {
+              const float t = act(xp[(size_t)y * W + xx], nan);
+              best = t > best ? t : best;
+            }
+          }
+        }
+        op[(size_t)yo * Wo + xq] = nan ? __builtin_nanf("") : best;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 int launch_channel_affine(const float* x, const float* scale, const float* shift, const float* res,
@@ -248,6 +322,23 @@ int launch_soft_aggregate(const float* dec, const int32_t* obj_begin, int B, int
   if (chunks > 1024) chunks = 1024;
   hipLaunchKernelGGL(soft_aggregate, dim3((unsigned)chunks, (unsigned)B), dim3(kThreads), 0, st, dec,
                      obj_begin, K, Hp, Wp, pad_l, pad_t, H, W, logit, prob);
+  return check_launch();
+}
+
+int launch_affine_relu_maxpool(const float* x, const float* scale, const float* shift, long long N,
+                               int C, int H, int W, float* out, hipStream_t st) {
+  if (!x || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0) return RMNET_E_INVALID_ARG;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long long planes = N * C;
+  const bool vec = W == 2 * Wo && (Wo & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  long long chunks = ((long long)Ho * (vec ? Wo >> 2 : Wo) + kThreads - 1) / kThreads;
+  if (chunks > 128) chunks = 128;
+  const dim3 grid((unsigned)chunks, (unsigned)(planes < 65535 ? planes : 65535));
+  if (vec)
+    hipLaunchKernelGGL(affine_relu_maxpool<true>, grid, dim3(kThreads), 0, st, x, scale, shift, C, planes, H, W, Ho, Wo, out);
+  else
+    hipLaunchKernelGGL(affine_relu_maxpool<false>, grid, dim3(kThreads), 0, st, x, scale, shift, C, planes, H, W, Ho, Wo, out);
   return check_launch();
 }
 

@@ -148,10 +148,13 @@ class EncoderMemory(nn.Module):
             from . import ops
             c = self.conv1
             t = F.conv2d(torch.cat((in_f, m, o), dim=1), self._w5, None, c.stride, c.padding)
-            c1 = ops.channel_affine(t, self._s1, self._b1, relu=True, out=t)
+            # bn1 -> relu -> maxpool in one pass; the stem activation c1 itself is not materialised
+            # (nothing downstream of the encoders reads it) and is returned as None
+            c1, pooled = None, ops.affine_relu_maxpool(t, self._s1, self._b1)
         else:
             c1 = self.relu(self.bn1(self.conv1(in_f) + self.conv1_m(m) + self.conv1_o(o)))
-        r2 = self.res2(self.maxpool(c1))
+            pooled = self.maxpool(c1)
+        r2 = self.res2(pooled)
         r3 = self.res3(r2)
         r4 = self.res4(r3)
         return r4, r3, r2, c1, in_f
@@ -170,10 +173,11 @@ class EncoderQuery(nn.Module):
         if getattr(self, '_fused', False) and in_f.is_cuda:
             from . import ops
             t = self.conv1(in_f)
-            c1 = ops.channel_affine(t, self._s1, self._b1, relu=True, out=t)
+            c1, pooled = None, ops.affine_relu_maxpool(t, self._s1, self._b1)   # (c1 not materialised)
         else:
             c1 = self.relu(self.bn1(self.conv1(in_f)))
-        r2 = self.res2(self.maxpool(c1))
+            pooled = self.maxpool(c1)
+        r2 = self.res2(pooled)
         r3 = self.res3(r2)
         r4 = self.res4(r3)
         return r4, r3, r2, c1, in_f

@@ -331,6 +331,27 @@ def soft_aggregate(dec, obj_begin, K, pad, want_prob=False):
     return logit, prob
 
 
+def affine_relu_maxpool(x, scale=None, shift=None):
+    """max_pool2d(relu(x * scale[c] + shift[c]), 3, stride=2, padding=1) in one pass (csrc/epilogue.hip):
+    the ResNet stem's bn1 -> relu -> maxpool without the full-resolution intermediate."""
+    _check(x, 'x')
+    if x.dim() != 4:
+        raise RuntimeError('x must be [N,C,H,W]')
+    N, C, H, W = x.shape
+    for t, n in ((scale, 'scale'), (shift, 'shift')):
+        if t is not None:
+            _check(t, n)
+            if t.numel() != C:
+                raise RuntimeError('%s must have C = %d elements' % (n, C))
+    out = torch.empty(N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1, dtype=x.dtype, device=x.device)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        rc = lib.rmnet_affine_relu_maxpool_f32(_ptr(x), _ptr(scale), _ptr(shift), N, C, H, W, _ptr(out),
+                                               _stream(x.device))
+    _lib.check(rc, 'rmnet_affine_relu_maxpool_f32')
+    return out
+
+
 def flow_affine(flow, m1, m2):
     """Device-resident variant: flow [H,W,2] f32 cuda, m1/m2 [2,3] f32 cuda -> [H,W,2]."""
     for t, n in ((flow, 'flow'), (m1, 'm1'), (m2, 'm2')):

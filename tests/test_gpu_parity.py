@@ -718,3 +718,22 @@ def test_inference_harness_single_rank(oracle_mod):
             assert got[i].dtype == torch.uint8 and got[i].shape == want.shape
             assert (got[i] == want).float().mean() > 0.999
     assert inference.video_costs(videos) == [3 * videos[0]['n_objects'], 4 * videos[1]['n_objects']]
+
+
+@pytest.mark.parametrize('N,C,H,W', [(2, 3, 7, 9), (1, 64, 240, 432), (1, 2, 1, 1), (3, 5, 16, 10), (2, 4, 9, 16)])
+def test_affine_relu_maxpool_is_the_torch_expression(N, C, H, W):
+    """rmnet_affine_relu_maxpool_f32 == F.max_pool2d(relu(x*scale + shift), 3, stride 2, padding 1),
+    bit for bit (odd sizes, borders, NaN propagation)."""
+    import torch.nn.functional as F
+    from rmnet_amd import ops
+    g = torch.Generator().manual_seed(H * 10 + W)
+    x = torch.randn(N, C, H, W, generator=g).to(dev())
+    sc, sh = torch.randn(C, generator=g).to(dev()), torch.randn(C, generator=g).to(dev())
+    v = lambda t: t.view(1, C, 1, 1)
+    want = F.max_pool2d(torch.relu(x * v(sc) + v(sh)), 3, stride=2, padding=1)
+    got = ops.affine_relu_maxpool(x, sc, sh)
+    assert got.shape == want.shape and torch.equal(got, want)
+    assert torch.equal(ops.affine_relu_maxpool(x), F.max_pool2d(torch.relu(x), 3, stride=2, padding=1))
+    x[0, 0, 0, 0] = float('nan')
+    got = ops.affine_relu_maxpool(x, sc, sh)
+    assert torch.isnan(got[0, 0, 0, 0]) and not torch.isnan(got[0, -1]).any()
