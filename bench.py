@@ -149,6 +149,7 @@ def main():
         net.fuse_for_inference()
     elif not args.no_fuse_epilogue and not args.channels_last:
         net.fuse_epilogues()
+        tfn.fuse_epilogues()
     if args.channels_last:
         net = net.to(memory_format=torch.channels_last)
         tfn = tfn.to(memory_format=torch.channels_last)

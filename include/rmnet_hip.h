@@ -159,8 +159,9 @@ int rmnet_rect_mask_f32(const float *x, int n, int C, int T, int h, int w, const
 
 /* C1 glue: per-channel affine + residual + ReLU in one pass over an NCHW fp32 activation,
  *   out[n,c,:] = act(x[n,c,:] * scale[c] + shift[c] + (res[n,c,:] * res_scale[c] + res_shift[c]))
- * scale / shift / res / res_scale / res_shift may each be NULL (1, 0, no residual, 1, 0); relu != 0
- * clamps at 0 (NaN propagates like torch.relu).  In place (out == x or out == res) is allowed.
+ * scale / shift / res / res_scale / res_shift may each be NULL (1, 0, no residual, 1, 0); act = relu:
+ * 0 none, 1 ReLU (NaN propagates like torch.relu), 2 LeakyReLU(0.1) (the slope of every activation of
+ * models/tiny_flownet.py).  In place (out == x or out == res) is allowed.
  * Replaces the elementwise passes the reference runs after every convolution in eval mode:
  * BatchNorm2d + ReLU + skip add of the torchvision Bottleneck (models/rmnet.py:66-80, 96-103 use
  * resnet50's layers) and conv bias + ReLU + skip add of ResBlock (models/rmnet.py:24-48), with

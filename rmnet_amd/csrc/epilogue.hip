@@ -33,11 +33,12 @@ __global__ __launch_bounds__(kThreads) void channel_affine(const float* x,   // 
     const int c = (int)(plane % C);
     const float sc = scale ? scale[c] : 1.0f, sh = shift ? shift[c] : 0.0f;
     const float rs = RES && rscale ? rscale[c] : 1.0f, rh = RES && rshift ? rshift[c] : 0.0f;
-    const float lo = relu ? 0.0f : -INFINITY;
+    const float lo = relu == 1 ? 0.0f : -INFINITY;
     const size_t base = (size_t)plane * HW;
     auto f = [&](float v, float r) {
       float y = v * sc + sh;
       if (RES) y = y + (r * rs + rh);
+      if (relu == 2) return y > 0.0f ? y : y * 0.1f;   // LeakyReLU(0.1) of TinyFlowNet
       return y < lo ? lo : y;          // NaN stays NaN (torch.relu semantics)
     };
     if (VEC4) {

@@ -252,7 +252,8 @@ def rect_mask(x, rects):
 def channel_affine(x, scale=None, shift=None, res=None, res_scale=None, res_shift=None, relu=False,
                    out=None):
     """out = act(x * scale[c] + shift[c] + (res * res_scale[c] + res_shift[c])) for NCHW fp32 ``x`` in
-    one pass (csrc/epilogue.hip).  ``out`` may be ``x`` or ``res`` (in place); default: a new tensor.
+    one pass (csrc/epilogue.hip); ``relu``: False, True, or 'leaky' (= LeakyReLU(0.1)).  ``out`` may be
+    ``x`` or ``res`` (in place); default: a new tensor.
     Replaces BatchNorm2d(eval) / conv bias / skip add / ReLU sequences around the convolutions."""
     _check(x, 'x')
     if x.dim() != 4:
@@ -278,7 +279,7 @@ def channel_affine(x, scale=None, shift=None, res=None, res_scale=None, res_shif
     lib = _lib.load()
     with torch.cuda.device(x.device):
         rc = lib.rmnet_channel_affine_f32(_ptr(x), _ptr(scale), _ptr(shift), _ptr(res), _ptr(res_scale),
-                                          _ptr(res_shift), 1 if relu else 0, N, C, H * W, _ptr(out),
+                                          _ptr(res_shift), 2 if relu == 'leaky' else (1 if relu else 0), N, C, H * W, _ptr(out),
                                           _stream(x.device))
     _lib.check(rc, 'rmnet_channel_affine_f32')
     return out

@@ -63,14 +63,15 @@ class TinyFlowNet(nn.Module):
         (img0, img1), pad = pad_divide_by([img0, img1], 64, img0.shape[2:])
         pair = torch.cat((F.interpolate(img0, scale_factor=0.5, mode='bilinear'),
                           F.interpolate(img1, scale_factor=0.5, mode='bilinear')), dim=1)
-        c2 = self.conv2(self.conv1(pair))
-        c3 = self.conv3_1(self.conv3(c2))
-        c4 = self.conv4_1(self.conv4(c3))
-        c5 = self.conv5_1(self.conv5(c4))
+        run = self._fused_block if getattr(self, '_fused', False) and pair.is_cuda else (lambda m, x: m(x))
+        c2 = run(self.conv2, run(self.conv1, pair))
+        c3 = run(self.conv3_1, run(self.conv3, c2))
+        c4 = run(self.conv4_1, run(self.conv4, c3))
+        c5 = run(self.conv5_1, run(self.conv5, c4))
 
-        cat4 = torch.cat((c4, self.deconv4(c5), self.upsampled_flow5_to_4(self.predict_flow5(c5))), 1)
-        cat3 = torch.cat((c3, self.deconv3(cat4), self.upsampled_flow4_to_3(self.predict_flow4(cat4))), 1)
-        cat2 = torch.cat((c2, self.deconv2(cat3), self.upsampled_flow3_to_2(self.predict_flow3(cat3))), 1)
+        cat4 = torch.cat((c4, run(self.deconv4, c5), self.upsampled_flow5_to_4(self.predict_flow5(c5))), 1)
+        cat3 = torch.cat((c3, run(self.deconv3, cat4), self.upsampled_flow4_to_3(self.predict_flow4(cat4))), 1)
+        cat2 = torch.cat((c2, run(self.deconv2, cat3), self.upsampled_flow3_to_2(self.predict_flow3(cat3))), 1)
         flow = F.interpolate(self.predict_flow2(cat2), scale_factor=8, mode='bilinear')
 
         lw, uw, lh, uh = pad
@@ -79,6 +80,24 @@ class TinyFlowNet(nn.Module):
         if lw + uw > 0:
             flow = flow[:, :, :, lw:flow.shape[3] - uw]
         return flow
+
+    @staticmethod
+    def _fused_block(block, x):
+        """conv / deconv (+bias) -> LeakyReLU(0.1) with the bias and the activation in ONE pass
+        (rmnet_channel_affine_f32, act 2) instead of two elementwise kernels."""
+        from . import ops
+        conv = block[0]
+        if isinstance(conv, nn.ConvTranspose2d):
+            t = F.conv_transpose2d(x, conv.weight, None, conv.stride, conv.padding)
+        else:
+            t = F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
+        return ops.channel_affine(t, None, conv.bias, relu='leaky', out=t)
+
+    def fuse_epilogues(self, enable=True):
+        """Bias + LeakyReLU of every block as one kernel (parameters untouched)."""
+        self.eval()
+        self._fused = bool(enable)
+        return self
 
     def forward(self, frames, device=None):
         b, n, _, h, w = frames.shape

@@ -737,3 +737,22 @@ def test_affine_relu_maxpool_is_the_torch_expression(N, C, H, W):
     x[0, 0, 0, 0] = float('nan')
     got = ops.affine_relu_maxpool(x, sc, sh)
     assert torch.isnan(got[0, 0, 0, 0]) and not torch.isnan(got[0, -1]).any()
+
+
+def test_tiny_flownet_fused_bias_leaky(golden_dir):
+    """TinyFlowNet.fuse_epilogues(): bias + LeakyReLU(0.1) in one kernel per block == the module graph
+    (channel_affine act 2 is bit-exact on its own: x + bias, then x > 0 ? x : 0.1 x)."""
+    import copy
+    from rmnet_amd import networks, ops
+    from rmnet_amd.tiny_flownet import TinyFlowNet
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 6, 9, 11, generator=g).to(dev())
+    b = torch.randn(6, generator=g).to(dev())
+    want = torch.nn.functional.leaky_relu(x + b.view(1, 6, 1, 1), 0.1)
+    assert torch.equal(ops.channel_affine(x, None, b, relu='leaky'), want)
+    tfn = networks.procedural_init_(TinyFlowNet(None)).to(dev()).eval()
+    fused = copy.deepcopy(tfn).fuse_epilogues()
+    frames = torch.randn(1, 3, 3, 96, 160, generator=g).to(dev())
+    with torch.no_grad():
+        a, f = tfn(frames), fused(frames)
+    assert float((a - f).abs().max()) <= 1e-4 * max(1.0, float(a.abs().max()))
