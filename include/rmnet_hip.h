@@ -172,7 +172,7 @@ int rmnet_channel_affine_f32(const float *x, const float *scale, const float *sh
 
 /* C1 glue: out = max_pool2d(relu(x * scale[c] + shift[c]), kernel 3, stride 2, padding 1), x [N,C,H,W] ->
  * out [N,C,(H-1)/2+1,(W-1)/2+1] fp32 NCHW; scale / shift may be NULL.  Replaces bn1 -> relu -> maxpool of
- * the ResNet-50 stems (torchvision layers used at models/rmnet.py:66-70, 96-98) without writing the
+ * the ResNet-50 stems (torchvision layers used at models/rmnet.py:74-76, 98-100) without writing the
  * full-resolution activation. */
 int rmnet_affine_relu_maxpool_f32(const float *x, const float *scale, const float *shift, long long N,
                                   int C, int H, int W, float *out, void *stream);

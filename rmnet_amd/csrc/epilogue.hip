@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kThreads) void soft_aggregate(const float* __restri
 
 // ---------------------------------------------------------------------------------------------
 // ResNet stem tail: relu(x * scale[c] + shift[c]) followed by MaxPool2d(3, stride 2, padding 1)
-// (torchvision resnet50's bn1 / relu / maxpool under models/rmnet.py:66-70, 96-98) in one pass: the
+// (torchvision resnet50's bn1 / relu / maxpool under models/rmnet.py:74-76, 98-100) in one pass: the
 // full-resolution activation (212 MB per encoder at eight 480p clips) is read once and never written.
 // Padding counts as -inf like torch's max_pool2d; a NaN in the window gives NaN.
 template <bool VEC4>
