@@ -44,7 +44,7 @@ class _Bottleneck(nn.Module):
                                             nn.BatchNorm2d(c_out))
 
     def forward(self, x):
-        if getattr(self, '_fused', False) and x.is_cuda:
+        if getattr(self, '_fused', False) and not self.training and x.is_cuda:
             return self._forward_fused(x)
         skip = x if self.downsample is None else self.downsample(x)
         y = self.relu(self.bn1(self.conv1(x)))
@@ -106,7 +106,7 @@ class ResBlock(nn.Module):
         self.conv2 = nn.Conv2d(outdim, outdim, 3, padding=1)
 
     def forward(self, x):
-        if getattr(self, '_fused', False) and x.is_cuda:
+        if getattr(self, '_fused', False) and not self.training and x.is_cuda:
             return self._forward_fused(x)
         r = self.conv2(F.relu(self.conv1(F.relu(x))))
         return (x if self.downsample is None else self.downsample(x)) + r
@@ -141,7 +141,7 @@ class EncoderMemory(nn.Module):
     def forward(self, in_f, in_m, in_o):
         m = in_m.unsqueeze(1).float()
         o = in_o.unsqueeze(1).float()
-        if getattr(self, '_fused', False) and in_f.is_cuda:
+        if getattr(self, '_fused', False) and not self.training and in_f.is_cuda:
             # conv1(f) + conv1_m(m) + conv1_o(o) is ONE 7x7 convolution over the 5 stacked input
             # channels with the three weights stacked the same way: two convolutions and two
             # full-resolution adds fewer, same sum up to fp32 summation order.
@@ -170,7 +170,7 @@ class EncoderQuery(nn.Module):
         self.res2, self.res3, self.res4 = trunk.layer1, trunk.layer2, trunk.layer3
 
     def forward(self, in_f):
-        if getattr(self, '_fused', False) and in_f.is_cuda:
+        if getattr(self, '_fused', False) and not self.training and in_f.is_cuda:
             from . import ops
             t = self.conv1(in_f)
             c1, pooled = None, ops.affine_relu_maxpool(t, self._s1, self._b1)   # (c1 not materialised)
@@ -195,7 +195,7 @@ class Refine(nn.Module):
 
     def forward(self, f, pm):
         s = self.ResFS(self.convFS(f))
-        if getattr(self, '_fused', False) and s.is_cuda and self.scale_factor == 2:
+        if getattr(self, '_fused', False) and not self.training and s.is_cuda and self.scale_factor == 2:
             from . import ops
             return self.ResMM(ops.upsample2x_add(pm, s, out=s))     # s + up in one pass
         up = F.interpolate(pm, scale_factor=self.scale_factor, mode='bilinear', align_corners=False)

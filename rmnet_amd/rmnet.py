@@ -212,7 +212,7 @@ class RMNet(nn.Module):
         else:                                       # reference-layout fp32 tensors (public segment())
             m4, _ = ops.memory_read(m_key, m_val, k4e.contiguous(), v4e.contiguous(), mem_rects, qry_rects,
                                     T=T, events=ev)
-        if obj_begin is not None and getattr(self, '_fused_tail', False):
+        if obj_begin is not None and (getattr(self, '_fused_tail', False) and not self.training):
             return ops.soft_aggregate(self.decoder(m4, r3e, r2e).contiguous(), obj_begin, K, pad, want_prob=True)
         ps = F.softmax(self.decoder(m4, r3e, r2e), dim=1)[:, 1]
         logit = self.soft_aggregation(ps, K, n_objects)
@@ -266,7 +266,7 @@ class RMNet(nn.Module):
         T = bank.stage(k4.contiguous(), v4.contiguous(), rects.view(B * K, 4).index_select(0, ctx.flat))
         if commit:
             bank.commit()
-        if getattr(self, '_fused_tail', False):             # warp fused into the box reduction
+        if (getattr(self, '_fused_tail', False) and not self.training):             # warp fused into the box reduction
             _, _, q_rects = ops.region_map(prev_mask.contiguous(), want_map=False, flow=cur_flow.contiguous(),
                                            cell_grid=(ctx.lw, ctx.lh, 16, ctx.h, ctx.w))
         else:

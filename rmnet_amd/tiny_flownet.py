@@ -63,7 +63,7 @@ class TinyFlowNet(nn.Module):
         (img0, img1), pad = pad_divide_by([img0, img1], 64, img0.shape[2:])
         pair = torch.cat((F.interpolate(img0, scale_factor=0.5, mode='bilinear'),
                           F.interpolate(img1, scale_factor=0.5, mode='bilinear')), dim=1)
-        run = self._fused_block if getattr(self, '_fused', False) and pair.is_cuda else (lambda m, x: m(x))
+        run = self._fused_block if getattr(self, '_fused', False) and not self.training and pair.is_cuda else (lambda m, x: m(x))
         c2 = run(self.conv2, run(self.conv1, pair))
         c3 = run(self.conv3_1, run(self.conv3, c2))
         c4 = run(self.conv4_1, run(self.conv4, c3))
