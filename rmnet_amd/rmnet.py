@@ -152,18 +152,23 @@ class RMNet(nn.Module):
         masks as pixel boxes + cell rectangles.  K/V are returned UN-masked."""
         B, K, H, W = masks.shape
         (frame, masks), _ = pad_divide_by([frame, masks.float()], 16, (H, W))
-        fs, ms, os_ = [], [], []
-        for b in range(B):
-            n = n_objects[b]
-            for o in range(1, n + 1):
-                fs.append(frame[b:b + 1])
-                ms.append(masks[b, o:o + 1])
-                if n == 1:
-                    os_.append(torch.zeros_like(masks[b, o:o + 1]))
-                else:  # same summation order as models/rmnet.py:224-226
-                    others = masks[b, 1:o].sum(0, keepdim=True) + masks[b, o + 1:n + 1].sum(0, keepdim=True)
-                    os_.append(others.clamp(0, 1))
-        r4 = self.encoder_memory(torch.cat(fs), torch.cat(ms), torch.cat(os_))[0]
+        if all(int(n) == 1 for n in n_objects):       # one object per clip: object i IS clip i, nothing to gather
+            f_in, m_in = frame, masks[:, 1]
+            o_in = torch.zeros_like(m_in)
+        else:
+            fs, ms, os_ = [], [], []
+            for b in range(B):
+                n = n_objects[b]
+                for o in range(1, n + 1):
+                    fs.append(frame[b:b + 1])
+                    ms.append(masks[b, o:o + 1])
+                    if n == 1:
+                        os_.append(torch.zeros_like(masks[b, o:o + 1]))
+                    else:  # same summation order as models/rmnet.py:224-226
+                        others = masks[b, 1:o].sum(0, keepdim=True) + masks[b, o + 1:n + 1].sum(0, keepdim=True)
+                        os_.append(others.clamp(0, 1))
+            f_in, m_in, o_in = torch.cat(fs), torch.cat(ms), torch.cat(os_)
+        r4 = self.encoder_memory(f_in, m_in, o_in)[0]
         k4, v4 = self.kv_memory(r4)
         h, w = k4.shape[-2:]
         _, bboxes, rects = ops.region_map(masks.contiguous(), want_map=False, cell_grid=(0, 0, 16, h, w))
