@@ -81,6 +81,12 @@ class TinyFlowNet(nn.Module):
             flow = flow[:, :, :, lw:flow.shape[3] - uw]
         return flow
 
+    def load_reference_state_dict(self, state_dict, strict=True):
+        """Accepts the reference's checkpoints with or without DataParallel's ``module.`` prefix
+        (core/inference.py:33-44)."""
+        clean = {(k[7:] if k.startswith('module.') else k): v for k, v in state_dict.items()}
+        return self.load_state_dict(clean, strict=strict)
+
     @staticmethod
     def _fused_block(block, x):
         """conv / deconv (+bias) -> LeakyReLU(0.1) with the bias and the activation in ONE pass

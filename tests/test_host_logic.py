@@ -32,6 +32,9 @@ def test_state_dict_keys_match_reference(golden_dir):
     # DataParallel-prefixed checkpoints load too (core/inference.py:43)
     sd = {'module.' + k: v for k, v in net.state_dict().items()}
     net.load_reference_state_dict(sd)
+    from rmnet_amd.tiny_flownet import TinyFlowNet
+    tfn = TinyFlowNet(None)
+    tfn.load_reference_state_dict({'module.' + k: v for k, v in tfn.state_dict().items()})
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
