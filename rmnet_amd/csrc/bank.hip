@@ -234,6 +234,9 @@ constexpr int kRThreads = 64 * (kProducers + kConsumers);  // 768 = 12 waves = 3
 #ifndef BK_SCHED
 #define BK_SCHED 1
 #endif
+#ifndef BK_CLK
+#define BK_CLK 0       // experiments only: per-workgroup shader-cycle / real-time stamps behind the plan records
+#endif
 
 // Workgroup = 12 waves (3 per SIMD), 64 compacted queries x one split of the tile list.
 //   waves 0-3  ("producers", static priority): S = K^T Q for 16 queries each (24 MFMAs per 32-cell
@@ -614,13 +617,26 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
   BK_STAMP();   // epilogue stores drained
 }
 
-constexpr int kMaxObj = 64;    // objects planned together in one launch (the launcher groups more)
+constexpr int kMaxObj = kBankMaxObj;    // objects planned together in one launch (the launcher groups more)
 
+// Launch-wide work list (stream-K with L2-friendly order).  Per object the work is the matrix
+// nqt(o) query tiles x njt(o) memory tiles.  ONE chunk length C (tiles per workgroup) is chosen for
+// the whole launch so that the chunks of all objects fill `target` CUs, whatever the box sizes.
+// Object o is cut into
+//   * nfull = njt / C column blocks of exactly C tiles: nqt * nfull chunks of ONE segment each,
+//     (block, query tile) in block-major order -- the nqt workgroups of a block walk the same K/V
+//     tiles in lockstep and sit on one XCD, so a tile comes from HBM once per L2 (measured: a plain
+//     query-tile-major stream-K order, where neighbours read different tiles, is 1.4-1.9x slower);
+//   * the remainder block of R = njt mod C tiles: its nqt * R tiles, query-tile-major, are cut into
+//     chunks of C again; such a chunk crosses query tiles and runs several SEGMENTS (all inside the
+//     same R <= C tile columns, which fit the L2).
+// (The previous integer split count per (object, query tile) left up to a quarter of the CUs idle:
+// 96 pairs -> 2 splits -> 192 workgroups.)  Every segment owns a partial slot (common.h, plan record).
 __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
-  __shared__ int o_njt[kMaxObj], o_m[kMaxObj], o_nqt[kMaxObj], o_ns[kMaxObj], o_base[kMaxObj];
+  __shared__ int o_njt[kMaxObj], o_m[kMaxObj], o_nqt[kMaxObj], o_cb[kMaxObj], o_sb[kMaxObj];
   __shared__ int o_rect[kMaxObj][4];
-  __shared__ int total_units;
+  __shared__ int plan_n, plan_c;
   char* Kl_ = lds;                                 // [ring slot][plane][8 KB]
   char* Pl_ = lds + 8 * kKbuf;                     // [buf][ntile][plane][lane*16]
   float* Al = reinterpret_cast<float*>(Pl_ + 2 * kPbuf);
@@ -628,6 +644,9 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   int* tarea = tpre + kMaxT + 4;
 
   const long long t_entry = (long long)__builtin_readcyclecounter();
+#if BK_CLK
+  const long long t_real = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
   const BankView& b = a.b;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -635,16 +654,12 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   if (producer && BK_PRIO > 0) __builtin_amdgcn_s_setprio(BK_PRIO);
 
   // ---- launch-wide plan, computed identically by every workgroup from the device-resident boxes
-  //      (no host sync): per object the query tiles and memory tiles; ONE chunk length C for the
-  //      whole launch such that  sum_o nqt(o) * ceil(njt(o) / C)  workgroup units fill `target`
-  //      CUs; object o is cut into nsplit(o) = ceil(njt(o) / C) nearly equal splits.  Objects with
-  //      boxes of different sizes (multi-object clips, several clips per GPU) then finish together,
-  //      which a per-object  target / (nqt * no)  rule does not give.
+  //      (no host sync)
   const int ng = a.nobj;
   const int lane0 = tid & 63;
   // Fast path (<= 12 objects, <= 64 memorised frames): wave w owns object w, lane t its frame t; the
-  // areas stay in registers, so the owner wave later builds the workgroup's tile prefix without a
-  // second trip to memory.  Otherwise: LDS atomics now, a reload of the own object's areas later.
+  // areas stay in registers, so the owner wave later builds the object's tile prefix without a
+  // second trip to memory.  Otherwise: LDS atomics now, a reload of the object's areas later.
   const bool fastplan = ng <= kProducers + kConsumers && a.T <= RMNET_WAVE;
   int my_ar = 0;
   if (fastplan) {
@@ -679,60 +694,50 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   __syncthreads();
   if (tid < RMNET_WAVE) {   // one wave, lane = object
     const int nqt = tid < ng ? o_nqt[tid] : 0, njt = tid < ng ? o_njt[tid] : 0;
-    const int work = wave_sum(nqt * njt);
-    const int nsmax = njt / kSplitMinTiles < 1 ? 1 : (njt / kSplitMinTiles > kSplitMax ? kSplitMax : njt / kSplitMinTiles);
-    int C = (work + a.target - 1) / a.target;
-    if (C < 1) C = 1;
-    int ns = 0;
-    for (int it = 0; it < 256; ++it) {
-      ns = njt == 0 ? 0 : (njt + C - 1) / C;
-      const bool capped = ns > nsmax;
-      if (capped) ns = nsmax;
-      (void)capped;
-      const int units = wave_sum(nqt * ns);
-      const int min_units = wave_sum(njt == 0 ? 0 : nqt);     // one split per pair
-      if (units <= a.target || units == min_units) break;     // fits, or cannot shrink any further
-      C += C >> 4 > 0 ? C >> 4 : 1;
-    }
-    int u = nqt * ns, incl = u;
+    const int W = wave_sum(nqt * njt), njt_max = wave_max(njt);
+    // smallest chunk length whose chunks fit `target` workgroups (sum_o nch(o) shrinks as C grows)
+    int C0 = max((W + a.target - 1) / a.target, bank_chunk_min(njt_max));
+    for (int it = 0; it < 1024 && wave_sum(bank_chunks(nqt, njt, C0).nch) > a.target; ++it) C0 += 1 + (C0 >> 5);
+    const BankChunks bc0 = bank_chunks(nqt, njt, C0);
+    int nch = bc0.nch, nsl = bc0.nch + (bc0.R > 0 ? nqt : 0);   // chunks; slots (a remainder chunk can add one per query tile)
+    const int my_ch = nch, my_sl = nsl;
 #pragma unroll
     for (int d = 1; d < RMNET_WAVE; d <<= 1) {
-      const int up = __shfl_up(incl, d);
-      if (tid >= d) incl += up;
+      const int u1 = __shfl_up(nch, d), u2 = __shfl_up(nsl, d);
+      if (tid >= d) { nch += u1; nsl += u2; }
     }
-    if (tid < ng) { o_ns[tid] = ns; o_base[tid] = incl - u; }
-    if (tid == RMNET_WAVE - 1) total_units = incl;
+    if (tid < ng) { o_cb[tid] = nch - my_ch; o_sb[tid] = nsl - my_sl; }
+    if (tid == RMNET_WAVE - 1) { plan_n = nch; plan_c = bc0.C; }
   }
   __syncthreads();
-  const int total = total_units;
+  auto sld = [](const int& x) { return __builtin_amdgcn_readfirstlane(x); };   // LDS value -> SGPR
+  const int nchunks = sld(plan_n), C = sld(plan_c);
   if ((int)blockIdx.x < ng && tid == 0) {   // plan record of object blockIdx.x for the combine kernel
     const int og = blockIdx.x;
     int32_t* pr = a.ws_plan + (size_t)(a.obj0 + og) * kPlanInts;
     const Rect r{o_rect[og][0], o_rect[og][1], o_rect[og][2], o_rect[og][3]};
-    pr[0] = r.area(); pr[1] = o_nqt[og]; pr[2] = o_ns[og]; pr[3] = o_m[og];
+    pr[0] = r.area(); pr[1] = o_nqt[og]; pr[2] = o_njt[og]; pr[3] = o_m[og];
     pr[4] = r.cx0; pr[5] = r.cx1; pr[6] = r.cy0; pr[7] = r.cy1;
-    pr[8] = a.slot0 + o_base[og];
+    pr[8] = a.slot0 + o_sb[og]; pr[9] = C; pr[10] = 0; pr[11] = 1;   // (mode 1 = chunked slots)
   }
-  if ((int)blockIdx.x >= total) return;
-  int U;
+  if ((int)blockIdx.x >= nchunks) return;
+  int c;
   {
-    const int q8 = total >> 3, r8 = total & 7, x = blockIdx.x & 7;   // XCD-contiguous logical ids
-    U = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (blockIdx.x >> 3);
+    const int q8 = nchunks >> 3, r8 = nchunks & 7, x = blockIdx.x & 7;   // XCD-contiguous logical ids
+    c = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (blockIdx.x >> 3);
   }
   int og = 0;
   for (int i = 1; i < ng; ++i)
-    if (o_base[i] <= U) og = i;             // (objects without units share the next one's base: the later one wins)
+    if (sld(o_cb[i]) <= c) og = i;          // (objects without chunks share the next one's base: the later one wins)
+  const int nqt = sld(o_nqt[og]), njt = sld(o_njt[og]);
+  const BankChunks bc = bank_chunks(nqt, njt, C);
+  const int cl = c - sld(o_cb[og]);         // chunk inside the object
+  const int lane = tid & 63;
   Walk wk;
   wk.o = a.obj0 + og;
-  wk.slot = a.slot0 + U;
-  wk.qr = Rect{o_rect[og][0], o_rect[og][1], o_rect[og][2], o_rect[og][3]};
+  wk.qr = Rect{sld(o_rect[og][0]), sld(o_rect[og][1]), sld(o_rect[og][2]), sld(o_rect[og][3])};
   wk.Mq = wk.qr.area();
-  const int nqt = o_nqt[og], nsplit = o_ns[og], njt = o_njt[og];
-  const int L = U - o_base[og];
-  const int s = L / nqt;
-  wk.qt = L - s * nqt;
-  wk.jt0 = (int)(((long long)s * njt) / nsplit);
-  wk.ntl = (int)(((long long)(s + 1) * njt) / nsplit) - wk.jt0;
+  const int slot_obj = a.slot0 + sld(o_sb[og]);
 
   // ---- this object's tile prefix over the T memorised frames
   if (fastplan) {
@@ -763,19 +768,52 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     if (tid == 0) tpre[0] = 0;
   }
   __syncthreads();
-  {
+  auto run_segment = [&]() {
     int lo = 0, hi = a.T;   // frame of the first tile
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
-      if (tpre[mid] <= wk.jt0) lo = mid; else hi = mid;
+      if (sld(tpre[mid]) <= wk.jt0) lo = mid; else hi = mid;
     }
     wk.t = lo;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));   // opaque per segment: keeps hipcc from hoisting the per-lane address
+                                   // arithmetic of the loops below out of the segment loop (it then spills)
+    if (producer)
+      producer_loop(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, ln, t_entry);
+    else
+      consumer_loop(a, wk, Kl_, Pl_, Al, tpre, wave, ln, t_entry);
+  };
+  if (cl < nqt * bc.nfull) {          // aligned chunk: (column block, query tile), one segment
+    const int blk = cl / nqt;
+    wk.qt = cl - blk * nqt;
+    wk.jt0 = blk * C;
+    wk.ntl = C;
+    wk.slot = slot_obj + cl;
+    run_segment();
+#if BK_CLK
+    if (tid == 0) {   // experiments: shader cycles vs constant-rate (100 MHz) clock of this workgroup
+      long long* cb = reinterpret_cast<long long*>(a.ws_plan + (size_t)(a.obj0 + a.nobj) * kPlanInts + 16) + 2 * blockIdx.x;
+      cb[0] = (long long)__builtin_readcyclecounter() - t_entry;
+      cb[1] = (long long)__builtin_amdgcn_s_memrealtime() - t_real;
+    }
+#endif
+    return;
   }
-  const int lane = tid & 63;
-  if (producer)
-    producer_loop(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, lane, t_entry);
-  else
-    consumer_loop(a, wk, Kl_, Pl_, Al, tpre, wave, lane, t_entry);
+  // remainder chunk: units [u0, u1) of the virtual line over the last R tile columns (common.h)
+  const int cr = cl - nqt * bc.nfull;
+  const int u0 = cr * C, u1 = u0 + C, span = bc.R + kSegCost;
+  bool first = true;
+  for (int qt = u0 / span; qt < nqt && qt * span < u1; ++qt) {
+    const int j0 = max(u0 - qt * span, 0), j1 = min(u1 - qt * span, bc.R);   // tiles of pair qt inside the chunk
+    if (j1 <= j0) continue;
+    wk.qt = qt;
+    wk.jt0 = bc.nfull * C + j0;
+    wk.ntl = j1 - j0;
+    wk.slot = slot_obj + nqt * bc.nfull + cr + qt;
+    if (!first) __syncthreads();      // the previous segment's LDS (K ring, P, alpha) is free
+    first = false;
+    run_segment();
+  }
 }
 
 }  // namespace
@@ -797,18 +835,14 @@ int launch_bank_main(const BankReadArgs& m, hipStream_t st) {
   a.ws_o = m.ws_o; a.ws_ml = m.ws_ml; a.ws_plan = m.ws_plan;
   a.T = m.T;
   a.qscale = 1.44269504088896341f / sqrtf((float)kDe);
-  // Objects are planned together in groups of <= kMaxObj; a group owns the partial slots
-  // [obj0 * slots, (obj0 + nobj) * slots), which always hold max(target, nobj * query tiles) units.
-  const int nqt_max = (m.h * m.w + 1 + kQT - 1) / kQT;
+  // Objects are planned together in groups of <= kMaxObj; a group's partial slots start at
+  // bank_group_slot0() and hold at most target + nobj * (query tiles) segments.
   for (int obj0 = 0; obj0 < m.no; obj0 += kMaxObj) {
     a.obj0 = obj0;
     a.nobj = m.no - obj0 < kMaxObj ? m.no - obj0 : kMaxObj;
-    a.slot0 = obj0 * m.slots;
-    const long long cap = (long long)a.nobj * m.slots;
-    a.target = (int)(cap < kSplitTargetSlots ? cap : kSplitTargetSlots);
-    const int floor_units = a.nobj * nqt_max;
-    const int grid = a.target > floor_units ? a.target : floor_units;
-    hipLaunchKernelGGL(bk_main, dim3(grid), dim3(kRThreads), 0, st, a);
+    a.slot0 = bank_group_slot0(obj0, m.h * m.w);
+    a.target = kSplitTargetSlots;
+    hipLaunchKernelGGL(bk_main, dim3(a.target), dim3(kRThreads), 0, st, a);
     if (int e = check_launch()) return e;
   }
   return RMNET_OK;

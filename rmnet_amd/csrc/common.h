@@ -143,10 +143,53 @@ __host__ __device__ inline BankPlan bank_plan(int Mq, int hw, int njt, int no, i
 }
 
 // Plan record written by a read kernel for the combine kernel (one small load instead of re-deriving
-// the plan from rectangles / areas): {Mq, nqt, nsplit, M, qr.cx0, qr.cx1, qr.cy0, qr.cy1, first
-// partial slot of the object, 0, 0, 0}; the partial of (split s, query tile qt) is slot
-// first + s * nqt + qt.
+// the plan from rectangles / areas), 12 ints per object:
+//   mode 0 (mr_main):  {Mq, nqt, nsplit, M, qr.cx0, qr.cx1, qr.cy0, qr.cy1, first partial slot of the
+//                       object, 0, 0, 0}; the partial of (split s, query tile qt) is slot first + s * nqt + qt;
+//   mode 1 (bk_main):  {Mq, nqt, njt, M, qr.cx0, qr.cx1, qr.cy0, qr.cy1, first partial slot sb of the
+//                       object, chunk length C, 0, 1}; slots of pair (o, qt), see bank_chunks():
+//                       sb + blk * nqt + qt            for the nfull aligned column blocks, then
+//                       sb + nqt * nfull + chunk + qt  for the remainder chunks that touch the pair.
 constexpr int kPlanInts = 12;
+
+// Chunking of one object's nqt x njt tile matrix into workgroup chunks of cost C (bank.hip):
+// nfull column blocks of exactly C tiles (one single-segment chunk per (block, query tile)), then
+// the remaining R tile columns, query-tile-major: pair qt occupies [qt * (R + kSegCost), + R) of a
+// virtual line that is cut every C units -- the kSegCost units after a pair's tiles are empty and
+// stand for the price of starting another segment (query fragments, K ring fill, first soft-max, a
+// 128 KB partial), so a chunk that crosses pair boundaries gets that many tiles less.
+#ifndef RMNET_SEG_COST
+#define RMNET_SEG_COST 4
+#endif
+constexpr int kSegCost = RMNET_SEG_COST;
+struct BankChunks { int C, nfull, R, nrem, nch; };
+__host__ __device__ inline BankChunks bank_chunks(int nqt, int njt, int C) {
+  BankChunks k;
+  k.C = C;
+  k.nfull = njt / C;
+  k.R = njt - k.nfull * C;
+  k.nrem = k.R > 0 ? (nqt * (k.R + kSegCost) - kSegCost + C - 1) / C : 0;
+  k.nch = nqt * k.nfull + k.nrem;
+  return k;
+}
+// Smallest chunk length a launch may use: a chunk must amortise its prologue and 128 KB partial
+// (kSplitMinTiles), and a pair may have at most kSplitMax partials (combine's LDS).
+__host__ __device__ inline int bank_chunk_min(int njt_max) {
+  const int cmin = (njt_max + kSplitMax - 4) / (kSplitMax - 3);   // njt / C <= kSplitMax - 3 aligned + <= 2 remainder
+  return cmin > kSplitMinTiles ? cmin : kSplitMinTiles;
+}
+
+// Partial slots of a bank read.  Objects are planned in groups of kBankMaxObj per launch; a group of n
+// objects needs at most kSplitTargetSlots chunks + n * nqt_max pair boundaries.
+constexpr int kBankMaxObj = 64;
+__host__ __device__ inline int bank_nqt_max(int hw) { return (hw + 1 + 63) / 64; }
+__host__ __device__ inline int bank_group_slot0(int obj0, int hw) {
+  return (obj0 / kBankMaxObj) * (kSplitTargetSlots + kBankMaxObj * bank_nqt_max(hw));
+}
+__host__ __device__ inline int bank_total_slots(int no, int hw) {
+  const int rem = no % kBankMaxObj;
+  return bank_group_slot0(no - rem, hw) + (rem ? kSplitTargetSlots + rem * bank_nqt_max(hw) : 0);
+}
 
 struct BankReadArgs {
   const void* bank;

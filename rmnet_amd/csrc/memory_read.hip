@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kThreads, 1) void mr_main(const KArgs a) {
     int32_t* pr = a.ws_plan + (size_t)o * kPlanInts;
     pr[0] = pl.Mq; pr[1] = pl.nqt; pr[2] = pl.nsplit; pr[3] = pl.M;
     pr[4] = pl.qr.cx0; pr[5] = pl.qr.cx1; pr[6] = pl.qr.cy0; pr[7] = pl.qr.cy1;
-    pr[8] = o * a.slots;
+    pr[8] = o * a.slots; pr[9] = 0; pr[10] = 0; pr[11] = 0;   // (mode 0, common.h)
   }
   if ((int)blockIdx.x >= nact) return;
   const int L = xcd_remap(blockIdx.x, nact);
@@ -377,19 +377,40 @@ __global__ __launch_bounds__(kThreads, kCombCh == 16 ? 6 : 5) void mr_combine(co
   __shared__ float Tm[kCombCh];
   const int tid = threadIdx.x, o = blockIdx.z;
   Plan pl;
-  int slot_base;
+  int p8, p9, mode;
   {
     const int32_t* pr = a.ws_plan + (size_t)o * kPlanInts;
     pl.Mq = pr[0]; pl.nqt = pr[1]; pl.nsplit = pr[2]; pl.M = pr[3];
     pl.qr = Rect{pr[4], pr[5], pr[6], pr[7]};
     pl.njt = 0;
-    slot_base = __builtin_amdgcn_readfirstlane(pr[8]);
+    p8 = __builtin_amdgcn_readfirstlane(pr[8]);
+    p9 = __builtin_amdgcn_readfirstlane(pr[9]);
+    mode = __builtin_amdgcn_readfirstlane(pr[11]);
   }
+  // Partial slots of one (object, query tile) pair (plan record, common.h): a strided run (mr_main's
+  // splits / bk_main's aligned column blocks) followed by a run of consecutive slots (bk_main's
+  // remainder chunks).
+  struct PairSlots {
+    int a0, na, sa, b0, count;
+    __device__ inline int slot(int s_) const { return s_ < na ? a0 + s_ * sa : b0 + (s_ - na); }
+  };
+  auto pair_slots = [&](int qt_) -> PairSlots {
+    if (mode == 0) return PairSlots{p8 + qt_, pl.nsplit, pl.nqt, 0, pl.nsplit};   // first + s * nqt + qt
+    const BankChunks bc = bank_chunks(pl.nqt, pl.nsplit, p9);                  // (mode 1 stores njt in [2], C in [9])
+    PairSlots r{p8 + qt_, bc.nfull, pl.nqt, 0, bc.nfull};
+    if (bc.R > 0) {
+      const int v0 = qt_ * (bc.R + kSegCost);                                     // the pair on the virtual line
+      const int cf = v0 / bc.C, cl = (v0 + bc.R - 1) / bc.C;                      // remainder chunks touching it
+      r.b0 = p8 + pl.nqt * bc.nfull + cf + qt_;
+      r.count += cl - cf + 1;
+    }
+    return r;
+  };
   const bool log2d = a.bank_area != nullptr;
   const int qi = tid & 63, sl = tid >> 6;
   const float n_out = (float)(a.T * a.hw - pl.M);
-  const float* __restrict__ ml = a.ws_ml + (size_t)slot_base * 2 * kQT;
-  const float* __restrict__ wo = a.ws_o + (size_t)slot_base * (size_t)kDo * kQT;
+  const float* __restrict__ ml = a.ws_ml;
+  const float* __restrict__ wo = a.ws_o;
   const bool fill = (int)blockIdx.x >= nqt_max;   // masked-row filler block
   const bool masked = REGIONAL && pl.Mq < a.hw;   // some query cell is masked: a mean slot exists
   const int qt = (int)blockIdx.x;
@@ -404,7 +425,9 @@ __global__ __launch_bounds__(kThreads, kCombCh == 16 ? 6 : 5) void mr_combine(co
     if (pl.Mq > 0 && y0 >= pl.qr.cy0 && y1 <= pl.qr.cy1) return;
   }
   const int d0 = blockIdx.y * kCombCh;
-  const size_t sstride = (size_t)pl.nqt * kDo * kQT;   // between the splits of one query tile
+  const PairSlots ps = fill ? PairSlots{0, 0, 1, 0, 0} : pair_slots(qt);
+  const int nsp = ps.count;                             // partials of this query tile
+  constexpr size_t kSlotF = (size_t)kDo * kQT;          // floats per partial slot
   auto ex = [&](float x) { return log2d ? exp2f(x) : expf(x); };
 
   // First batch of this tile's partial fragments: requested NOW, before the weights are known, so
@@ -413,18 +436,18 @@ __global__ __launch_bounds__(kThreads, kCombCh == 16 ? 6 : 5) void mr_combine(co
   // are clamped (re-read) and get weight 0.
   constexpr int kU = kCombDt >= 8 ? 1 : 8 / kCombDt;   // splits per batch: 8 independent 16-byte loads in flight
   constexpr int kE = kU < 4 ? kU : 4;    // splits of the early batch (small: duplicates cost bandwidth)
-  const float* __restrict__ psrc = wo + (size_t)(fill ? 0 : qt) * kDo * kQT + partial_frag_offset(d0 >> 4, sl, qi);
+  const float* __restrict__ psrc = wo + partial_frag_offset(d0 >> 4, sl, qi);
   f32x4 v0[kE][kCombDt];
 #pragma unroll
   for (int u = 0; u < kE; ++u)
 #pragma unroll
     for (int k = 0; k < kCombDt; ++k) v0[u][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (!fill && pl.nsplit > 0 && !(RMNET_COMB_ABL & 8)) {   // (no split at all when every memory cell is masked: the read-out is 0)
+  if (!fill && nsp > 0 && !(RMNET_COMB_ABL & 8)) {   // (no split at all when every memory cell is masked: the read-out is 0)
 #pragma unroll
     for (int u = 0; u < kE; ++u)
 #pragma unroll
       for (int k = 0; k < kCombDt; ++k)
-        v0[u][k] = *reinterpret_cast<const f32x4*>(psrc + (size_t)min(u, pl.nsplit - 1) * sstride + (size_t)k * 1024);
+        v0[u][k] = *reinterpret_cast<const f32x4*>(psrc + (size_t)ps.slot(min(u, nsp - 1)) * kSlotF + (size_t)k * 1024);
   }
 
   // Everything the weights need is requested before the first barrier: this tile's (m, l) pairs of up
@@ -436,20 +459,21 @@ __global__ __launch_bounds__(kThreads, kCombCh == 16 ? 6 : 5) void mr_combine(co
   __shared__ float red2[4][kQT];
   __shared__ float tp[kTmParts][kCombCh];
   const int qtm = pl.Mq >> 6, mq = pl.Mq & 63;
+  const PairSlots pm = masked ? pair_slots(qtm) : PairSlots{0, 0, 1, 0, 0};   // the mean slot's query tile
   float m_r[kMl], l_r[kMl];
   if (!fill) {
 #pragma unroll
     for (int j = 0; j < kMl; ++j) {
       const int sj = sl + 4 * j;
-      const float* e = ml + ((size_t)(min(sj, max(pl.nsplit - 1, 0)) * pl.nqt + qt) * 2) * kQT;
-      const bool on = sj < pl.nsplit;
+      const float* e = ml + ((size_t)ps.slot(min(sj, max(nsp - 1, 0))) * 2) * kQT;
+      const bool on = sj < nsp;
       m_r[j] = on ? e[qi] : -INFINITY;
       l_r[j] = on ? e[kQT + qi] : 0.0f;
     }
   }
   float mm = -INFINITY, lm = 0.0f;        // mean slot (wave 0, lane = split)
-  if (masked && tid < RMNET_WAVE && tid < pl.nsplit) {
-    const float* e = ml + ((size_t)(tid * pl.nqt + qtm) * 2) * kQT;
+  if (masked && tid < RMNET_WAVE && tid < pm.count) {
+    const float* e = ml + ((size_t)pm.slot(tid) * 2) * kQT;
     mm = e[mq];
     lm = e[kQT + mq];
   }
@@ -459,7 +483,7 @@ __global__ __launch_bounds__(kThreads, kCombCh == 16 ? 6 : 5) void mr_combine(co
     float mloc = -INFINITY;
 #pragma unroll
     for (int j = 0; j < kMl; ++j) mloc = fmaxf(mloc, m_r[j]);
-    for (int sj = sl + 4 * kMl; sj < pl.nsplit; sj += 4) mloc = fmaxf(mloc, ml[((size_t)(sj * pl.nqt + qt) * 2) * kQT + qi]);
+    for (int sj = sl + 4 * kMl; sj < nsp; sj += 4) mloc = fmaxf(mloc, ml[((size_t)ps.slot(sj) * 2) * kQT + qi]);
     red[sl][qi] = mloc;
   }
   if (masked && tid < RMNET_WAVE) {
@@ -467,7 +491,7 @@ __global__ __launch_bounds__(kThreads, kCombCh == 16 ? 6 : 5) void mr_combine(co
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) mtot = fmaxf(mtot, __shfl_xor(mtot, d));
     if (n_out > 0.0f) mtot = fmaxf(mtot, 0.0f);
-    const float wgt = tid < pl.nsplit ? ex(mm - mtot) : 0.0f;
+    const float wgt = tid < pm.count ? ex(mm - mtot) : 0.0f;
     float ltot = lm * wgt;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) ltot += __shfl_xor(ltot, d);
@@ -480,9 +504,9 @@ __global__ __launch_bounds__(kThreads, kCombCh == 16 ? 6 : 5) void mr_combine(co
   float tm_acc = 0.0f;
   if (masked) {   // 256 threads = kCombCh channels x kTmParts interleaved subsets of the splits
     const int chn = tid % kCombCh, part = tid / kCombCh;
-    const float* __restrict__ src = wo + (size_t)qtm * kDo * kQT + partial_elem_offset(mq, d0 + chn);
+    const float* __restrict__ src = wo + partial_elem_offset(mq, d0 + chn);
 #pragma unroll 4
-    for (int s2 = part; s2 < pl.nsplit; s2 += kTmParts) tm_acc += Wm[s2] * src[(size_t)s2 * sstride];
+    for (int s2 = part; s2 < pm.count; s2 += kTmParts) tm_acc += Wm[s2] * src[(size_t)pm.slot(s2) * kSlotF];
   }
   if (!fill) {
     float mtot = fmaxf(fmaxf(red[0][qi], red[1][qi]), fmaxf(red[2][qi], red[3][qi]));
@@ -495,8 +519,8 @@ __global__ __launch_bounds__(kThreads, kCombCh == 16 ? 6 : 5) void mr_combine(co
       if (sj < kMaxSplits) Wt[sj][qi] = wgt;
       lloc += l_r[j] * wgt;
     }
-    for (int sj = sl + 4 * kMl; sj < pl.nsplit; sj += 4) {
-      const float* e = ml + ((size_t)(sj * pl.nqt + qt) * 2) * kQT;
+    for (int sj = sl + 4 * kMl; sj < nsp; sj += 4) {
+      const float* e = ml + ((size_t)ps.slot(sj) * 2) * kQT;
       const float wgt = ex(e[qi] - mtot);
       Wt[sj][qi] = wgt;
       lloc += e[kQT + qi] * wgt;
@@ -539,18 +563,18 @@ __global__ __launch_bounds__(kThreads, kCombCh == 16 ? 6 : 5) void mr_combine(co
     const float* __restrict__ src = psrc;
 #pragma unroll
     for (int u = 0; u < kE; ++u) {
-      const float wgt = u < pl.nsplit ? Wt[u][q] : 0.0f;   // (clamped duplicates of the early batch)
+      const float wgt = u < nsp ? Wt[u][q] : 0.0f;   // (clamped duplicates of the early batch)
 #pragma unroll
       for (int k = 0; k < kCombDt; ++k) acc[k] += wgt * v0[u][k];
     }
     int s = kE;
-    for (; s + kU <= pl.nsplit; s += kU) {
+    for (; s + kU <= nsp; s += kU) {
       f32x4 v[kU][kCombDt];
 #pragma unroll
       for (int u = 0; u < kU; ++u)
 #pragma unroll
         for (int k = 0; k < kCombDt; ++k)
-          v[u][k] = *reinterpret_cast<const f32x4*>(src + (size_t)(s + u) * sstride + (size_t)k * 1024);
+          v[u][k] = *reinterpret_cast<const f32x4*>(src + (size_t)ps.slot(s + u) * kSlotF + (size_t)k * 1024);
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
         const float wgt = Wt[s + u][q];
@@ -558,11 +582,11 @@ __global__ __launch_bounds__(kThreads, kCombCh == 16 ? 6 : 5) void mr_combine(co
         for (int k = 0; k < kCombDt; ++k) acc[k] += wgt * v[u][k];
       }
     }
-    for (; s < pl.nsplit; ++s) {
+    for (; s < nsp; ++s) {
       const float wgt = Wt[s][q];
 #pragma unroll
       for (int k = 0; k < kCombDt; ++k)
-        acc[k] += wgt * *reinterpret_cast<const f32x4*>(src + (size_t)s * sstride + (size_t)k * 1024);
+        acc[k] += wgt * *reinterpret_cast<const f32x4*>(src + (size_t)ps.slot(s) * kSlotF + (size_t)k * 1024);
     }
 #pragma unroll
     for (int k = 0; k < kCombDt; ++k)
@@ -809,9 +833,12 @@ int launch_memory_read(const MemReadArgs& m, hipStream_t st) {
 }
 
 size_t bank_read_ws_bytes(int no, int h, int w) {
-  const size_t slots = slots_for(no, h * w);
-  return align256((size_t)no * slots * kDo * kQT * 4) + align256((size_t)no * slots * 2 * kQT * 4) +
-         align256((size_t)no * kPlanInts * 4);
+  const size_t slots = bank_total_slots(no, h * w);
+  return align256(slots * kDo * kQT * 4) + align256(slots * 2 * kQT * 4) + align256((size_t)no * kPlanInts * 4)
+#ifdef BK_CLK
+         + 8192
+#endif
+      ;
 }
 
 int launch_bank_read(BankReadArgs& m, hipStream_t st) {
@@ -821,12 +848,11 @@ int launch_bank_read(BankReadArgs& m, hipStream_t st) {
   if (m.no > 65535 || m.Tcap > kMaxT) return RMNET_E_UNSUPPORTED;
   if (!m.ws || m.ws_bytes < bank_read_ws_bytes(m.no, m.h, m.w)) return RMNET_E_WORKSPACE;
   const int hw = m.h * m.w;
-  m.slots = slots_for(m.no, hw);
+  const size_t tslots = bank_total_slots(m.no, hw);
+  m.slots = (int)tslots;
   m.ws_o = static_cast<float*>(m.ws);
-  m.ws_ml = reinterpret_cast<float*>(static_cast<char*>(m.ws) +
-                                     align256((size_t)m.no * m.slots * kDo * kQT * 4));
-  m.ws_plan = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(m.ws_ml) +
-                                         align256((size_t)m.no * m.slots * 2 * kQT * 4));
+  m.ws_ml = reinterpret_cast<float*>(static_cast<char*>(m.ws) + align256(tslots * kDo * kQT * 4));
+  m.ws_plan = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(m.ws_ml) + align256(tslots * 2 * kQT * 4));
   if (m.ev_start && hipEventRecord(m.ev_start, st) != hipSuccess) return RMNET_E_LAUNCH;
   if (int e = launch_bank_main(m, st)) return e;
   if (m.ev_mid && hipEventRecord(m.ev_mid, st) != hipSuccess) return RMNET_E_LAUNCH;

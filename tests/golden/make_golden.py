@@ -16,7 +16,12 @@ are pre-seeded in ``sys.modules``:
 ``flow_affine`` vectors come from the reference's own C++ compiled by oracle/Makefile
 (oracle/_ref/flow_affine_transformation.so).
 
-    python tests/golden/make_golden.py        # rewrites the .npz files next to this script
+``region_boxes`` additionally pins the region map's box finder against the reference's own Python
+box finder (utils/helpers.py:93-102 get_bounding_boxes): with n_pts_threshold = 1 and
+n_bbox_loose_pixels = 0 the CUDA kernel reduces to it (reg_att_map_generator.cu:63-74 with L = 0).
+
+    python tests/golden/make_golden.py                   # rewrites every fixture next to this script
+    python tests/golden/make_golden.py region_boxes msi  # only the named sections
 """
 
 import importlib.util
@@ -66,15 +71,7 @@ def _load_ref_flow_ext():
     return mod
 
 
-def main():
-    _install_stand_ins()
-    import models.rmnet as ref_rmnet          # the reference, imported in place
-    import models.tiny_flownet as ref_tfn
-    import utils.helpers as ref_helpers
-    torch.manual_seed(0)
-    torch.set_grad_enabled(False)
-    rng = np.random.RandomState(1234)
-
+def section_memory_reader(ref_rmnet, ref_tfn, ref_helpers, rng):
     # ---------------------------------------------------------------- MemoryReader (M1)
     reader = ref_rmnet.MemoryReader()
     cases = {}
@@ -119,8 +116,12 @@ def main():
             zero_mem=[[(0, 6, 0, 4), (1, 4, 1, 3), (1, 0, 1, 0)]], zero_qry=[(1, 0, 1, 0)])
     mr_case('tiny_p', 1, 16, 32, 1, 3, 4, keep_p=True)
     mr_case('peaky', 1, 128, 512, 2, 4, 5, scale=3.0)      # large logits: exercises the running max
-    np.savez_compressed(os.path.join(HERE, 'memory_reader.npz'), **cases)
+    if 'memory_reader' in WRITE:
+        np.savez_compressed(os.path.join(HERE, 'memory_reader.npz'), **cases)
 
+
+
+def section_flow_affine(ref_rmnet, ref_tfn, ref_helpers, rng):
     # ---------------------------------------------------------------- flow affine (F1)
     ext = _load_ref_flow_ext()
     fa = {}
@@ -142,6 +143,9 @@ def main():
     fa_case('half_ties', 16, 24, [1, 0, 0.5, 0, 1, -0.5], [1, 0, 1.5, 0, 1, 2.5], 0.0)  # round half away
     np.savez_compressed(os.path.join(HERE, 'flow_affine.npz'), **fa)
 
+
+
+def section_pad(ref_rmnet, ref_tfn, ref_helpers, rng):
     # ---------------------------------------------------------------- pad_divide_by (H1)
     pads = {}
     for (h, w, d) in [(480, 854, 16), (480, 910, 16), (720, 1280, 16), (150, 250, 16), (480, 854, 64),
@@ -151,6 +155,9 @@ def main():
     with open(os.path.join(HERE, 'pad_divide_by.json'), 'w') as f:
         json.dump(pads, f, indent=1, sort_keys=True)
 
+
+
+def section_clip(ref_rmnet, ref_tfn, ref_helpers, rng):
     # ---------------------------------------------------------------- RMNet glue (P1-P5, A1)
     net = ref_rmnet.RMNet(None)
     networks.procedural_init_(net)
@@ -181,18 +188,96 @@ def main():
     g['clip.est_t1'] = est[:, 1].numpy()
     np.savez_compressed(os.path.join(HERE, 'rmnet_clip.npz'), **g)
 
+
+
+def section_tiny_flownet(ref_rmnet, ref_tfn, ref_helpers, rng):
     # ---------------------------------------------------------------- TinyFlowNet (C2)
     tfn = ref_tfn.TinyFlowNet(None)
     networks.procedural_init_(tfn)
     tfn.eval()
+    frames = synthetic_clip(4, 3, 150, 250, seed=3)[0]
     small = frames[:, :2, :, :70, :100].contiguous()
     fl = tfn(small)
     np.savez_compressed(os.path.join(HERE, 'tiny_flownet.npz'), frames=small.numpy(), flows=fl.numpy(),
                         state_keys=np.array(sorted(tfn.state_dict().keys())))
+
+
+def section_region_boxes(ref_rmnet, ref_tfn, ref_helpers, rng):
+    # ---------------------------------------------------------------- region map boxes (G1)
+    # The reference's own box finder on thresholded soft masks (tests/golden/cases.py builds the masks);
+    # -1 rows = it returned None (empty channel).
+    import cases
+    out = {}
+    for i, (B, K, H, W) in enumerate(cases.REGION_BOX_SHAPES):
+        m = cases.region_box_case(i)
+        tight = np.full((B * K, 4), -1, np.int32)
+        for b in range(B):
+            for k in range(K):
+                bb = ref_helpers.get_bounding_boxes(m[b, k] >= 0.5)
+                if bb[0] is not None:
+                    tight[b * K + k] = [int(v) for v in bb]
+        out['case%02d.tight' % i] = tight
+        out['case%02d.checksum' % i] = np.float64(m.astype(np.float64).sum())   # guards the shared generator
+    np.savez_compressed(os.path.join(HERE, 'region_boxes.npz'), **out)
+
+
+def section_msi(ref_rmnet, ref_tfn, ref_helpers, rng):
+    # ---------------------------------------------------------------- multi_scale_inference (H1)
+    import cases
+    from types import SimpleNamespace
+    net = ref_rmnet.RMNet(None)
+    networks.procedural_init_(net)
+    net.eval()
+    tfn = ref_tfn.TinyFlowNet(None)
+    networks.procedural_init_(tfn)
+    tfn.eval()
+    c = cases.MSI_CLIP
+    frames, masks, _, n_objects = synthetic_clip(c['N'], c['K'], c['H'], c['W'], seed=c['seed'], size=c['size'])
+    out = {}
+    for name, scales, flip in cases.MSI_CASES:
+        cfg = SimpleNamespace(TEST=SimpleNamespace(FRAME_SCALES=scales, FLIP_LR=flip,
+                                                   MEMORIZE_EVERY=c['memorize_every']))
+        flows, probs = ref_helpers.multi_scale_inference(cfg, tfn, net, frames, masks, n_objects)
+        out[name + '.flows'] = flows.numpy().astype(np.float16)            # (compact: compared at 2e-3)
+        out[name + '.probs'] = probs.numpy().astype(np.float16)
+        out[name + '.argmax'] = probs.argmax(dim=2).numpy().astype(np.uint8)
+    # var_or_cuda on the CPU-only container: contiguous copy, device unchanged (utils/helpers.py:16-24)
+    x = torch.arange(24.).view(2, 3, 4).transpose(1, 2)
+    y = ref_helpers.var_or_cuda(x)
+    out['var_or_cuda.contiguous'] = np.array([bool(y.is_contiguous()), bool(torch.equal(x, y))])
+    np.savez_compressed(os.path.join(HERE, 'multi_scale_inference.npz'), **out)
+
+
+WRITE = set()      # sections whose files are rewritten by this run
+
+SECTIONS = [('memory_reader', section_memory_reader), ('flow_affine', section_flow_affine), ('pad', section_pad),
+            ('clip', section_clip), ('tiny_flownet', section_tiny_flownet), ('region_boxes', section_region_boxes),
+            ('msi', section_msi)]
+
+
+def main(argv):
+    _install_stand_ins()
+    sys.path.insert(0, HERE)
+    import models.rmnet as ref_rmnet          # the reference, imported in place
+    import models.tiny_flownet as ref_tfn
+    import utils.helpers as ref_helpers
+    torch.set_grad_enabled(False)
+    want = set(argv) or {n for n, _ in SECTIONS}
+    unknown = want - {n for n, _ in SECTIONS}
+    assert not unknown, 'unknown sections: %s' % sorted(unknown)
+    WRITE.update(want)
+    if 'flow_affine' in want:
+        want.add('memory_reader')     # the two share one random stream (memory_reader draws first); replayed, not rewritten
+    shared = np.random.RandomState(1234)
+    for name, fn in SECTIONS:
+        if name in want:
+            torch.manual_seed(0)
+            fn(ref_rmnet, ref_tfn, ref_helpers, shared if name in ('memory_reader', 'flow_affine') else np.random.RandomState(99))
+            print('section', name, 'done' if name in WRITE else 'replayed (not written)')
     print('golden fixtures written to', HERE)
     for fn in sorted(os.listdir(HERE)):
-        print('  %-24s %8d B' % (fn, os.path.getsize(os.path.join(HERE, fn))))
+        print('  %-28s %8d B' % (fn, os.path.getsize(os.path.join(HERE, fn))))
 
 
 if __name__ == '__main__':
-    main()
+    main(sys.argv[1:])

@@ -1,0 +1,37 @@
+# -*- coding: utf-8 -*-
+"""Shader clock under bk_main (needs a library built with -DBK_CLK=1): per workgroup, elapsed shader
+cycles (s_memtime) vs elapsed constant-rate ticks (s_memrealtime, 100 MHz).
+    python tools/bk_clk.py <no> <q_h> <q_w> <m_h> <m_w> [T]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, numpy as np
+from rmnet_amd import ops, _lib
+no, qh, qw, mh, mw = [int(x) for x in sys.argv[1:6]]
+T = int(sys.argv[6]) if len(sys.argv) > 6 else 5
+h, w = 30, 54
+dev = torch.device('cuda', 0)
+g = torch.Generator().manual_seed(0)
+mk = (torch.randn(no, 128, T, h, w, generator=g) * 0.6).to(dev)
+mv = torch.randn(no, 512, T, h, w, generator=g).to(dev)
+qk = (torch.randn(no, 128, h, w, generator=g) * 0.6).to(dev)
+qv = torch.randn(no, 512, h, w, generator=g).to(dev)
+qr = torch.tensor([(2, 2 + qw - 1, 1, 1 + qh - 1)] * no, dtype=torch.int32, device=dev)
+mr = torch.tensor([(3, 3 + mw - 1, 2, 2 + mh - 1)] * no, dtype=torch.int32, device=dev)
+bank = ops.MemoryBank(no, T, h, w, dev)
+for t in range(T):
+    bank.append(t, mk[:, :, t].contiguous(), mv[:, :, t].contiguous(), mr)
+lib = _lib.load()
+nb = lib.rmnet_bank_read_workspace_bytes(no, h, w)
+ws = torch.zeros(nb, dtype=torch.uint8, device=dev)
+for _ in range(20):
+    bank.read(T, qk, qv, qr, ws=ws)
+torch.cuda.synchronize()
+tail = ws[nb - 8192 - 256:].cpu().numpy()
+# the stamps start 64 bytes after the plan records (which end somewhere inside the last 256-byte pad)
+plan_end = (no * 12 * 4)
+off = 256 - ((-plan_end) % 256 if plan_end % 256 else 0)
+raw = ws[nb - 8192 - ((plan_end + 255) // 256 * 256) + plan_end + 64:][:256 * 16].view(torch.int64).cpu().numpy().reshape(-1, 2)
+raw = raw[(raw[:, 1] > 0) & (raw[:, 0] > 0)]
+ghz = raw[:, 0] / (raw[:, 1] * 10.0)   # cycles per ns (100 MHz real-time ticks = 10 ns each)
+print('no=%d: %d workgroups stamped; shader cycles %.0f..%.0f, real us %.1f..%.1f, clock GHz mean %.3f min %.3f max %.3f'
+      % (no, len(raw), raw[:, 0].min(), raw[:, 0].max(), raw[:, 1].min() / 100.0, raw[:, 1].max() / 100.0, ghz.mean(), ghz.min(), ghz.max()))

@@ -1,0 +1,39 @@
+# -*- coding: utf-8 -*-
+"""bk_main / mr_combine timing with identical, explicitly sized boxes for every object:
+    python tools/chunk_bench.py <no> <q_h> <q_w> <m_h> <m_w> [T]
+(lets a launch be made of exactly aligned chunks: e.g. 8 objects, query 21x24 (8 tiles), memory 24x32
+(24 tiles per frame) -> 256 single-segment chunks of 30 tiles)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, numpy as np
+from rmnet_amd import ops
+from bench import HipEvents
+no, qh, qw, mh, mw = [int(x) for x in sys.argv[1:6]]
+T = int(sys.argv[6]) if len(sys.argv) > 6 else 5
+h, w = 30, 54
+dev = torch.device('cuda', 0)
+g = torch.Generator().manual_seed(0)
+mk = (torch.randn(no, 128, T, h, w, generator=g) * 0.6).to(dev)
+mv = torch.randn(no, 512, T, h, w, generator=g).to(dev)
+qk = (torch.randn(no, 128, h, w, generator=g) * 0.6).to(dev)
+qv = torch.randn(no, 512, h, w, generator=g).to(dev)
+qr = torch.tensor([(2, 2 + qw - 1, 1, 1 + qh - 1)] * no, dtype=torch.int32, device=dev)
+mr = torch.tensor([(3, 3 + mw - 1, 2, 2 + mh - 1)] * no, dtype=torch.int32, device=dev)
+bank = ops.MemoryBank(no, T, h, w, dev)
+for t in range(T):
+    bank.append(t, mk[:, :, t].contiguous(), mv[:, :, t].contiguous(), mr)
+reps = 40
+ev = HipEvents(3 * reps)
+floor = ev.floor_us(torch.cuda.current_stream(dev).cuda_stream)
+for _ in range(5):
+    bank.read(T, qk, qv, qr)
+torch.cuda.synchronize()
+for i in range(reps):
+    bank.read(T, qk, qv, qr, events=tuple(ev.ev[3 * i:3 * i + 3]))
+torch.cuda.synchronize()
+bm = [ev.elapsed_ms(ev.ev[3 * i], ev.ev[3 * i + 1]) * 1e3 - floor for i in range(reps)]
+bc = [ev.elapsed_ms(ev.ev[3 * i + 1], ev.ev[3 * i + 2]) * 1e3 - floor for i in range(reps)]
+nqt = (qh * qw + 1 + 63) // 64
+njt = T * ((mh * mw + 31) // 32)
+print('no=%d nqt=%d njt=%d pairs*tiles=%d | bk_main avg %.2f min %.2f us | combine avg %.2f min %.2f us (event floor %.2f us subtracted)'
+      % (no, nqt, njt, no * nqt * njt, np.mean(bm), np.min(bm), np.mean(bc), np.min(bc), floor))
