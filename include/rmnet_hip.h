@@ -101,10 +101,16 @@ int rmnet_boxes_to_cell_rects_i32(const int32_t *bboxes, int n_boxes, int k_per_
  *   flags  RMNET_MR_* below.
  * The fast path needs De == 128 and Do == 512 (RMNet's sizes, models/rmnet.py:185-186); other
  * sizes run a generic (slow, still on-GPU) path that needs the p-sized workspace.
- * Floating point: fp32 MFMA accumulate; parity with the reference is a tolerance (see tests).
+ * Fast path arithmetic: the memory is first staged (one launch, inside `workspace`) into a transient
+ * split-fp16 bank (below) and read with 3-term fp16 MFMAs, fp32 accumulate -- fp32-class accuracy for
+ * |K|, |V| < 1023.5.  The staging pass counts elements outside that window on the device; if there is
+ * one (or a NaN / Inf), the exact-fp32 MFMA kernel (v_mfma_f32_16x16x4_f32, no range limit, ~4x slower)
+ * does the read instead -- chosen on the device, no host synchronisation, no silent saturation.
+ * RMNET_MR_EXACT_FP32 forces the exact kernel.  Parity with the reference is a tolerance (see tests).
  * ------------------------------------------------------------------------------------------- */
 #define RMNET_MR_DEFAULT 0
 #define RMNET_MR_FORCE_GENERIC 1 /* use the generic path even for De=128, Do=512 (testing) */
+#define RMNET_MR_EXACT_FP32 2    /* fast shape only: skip the split-fp16 bank, run the exact-fp32 MFMA kernel */
 
 size_t rmnet_memory_read_workspace_bytes(int no, int De, int Do, int T, int h, int w, int flags);
 int rmnet_memory_read_f32(const float *m_key, const float *m_val, const float *q_key,
@@ -139,10 +145,16 @@ int rmnet_memory_read_f32_ev(const float *m_key, const float *m_val, const float
  *   rmnet_bank_read_f32: read the first T slots with q_key [no,128,h,w], q_val [no,512,h,w] and
  *       query rectangles qry_rects [no,4] (NULL = all cells) -> mem_val [no,1024,h,w], identical in
  *       meaning to rmnet_memory_read_f32 with the same rectangles.  Arithmetic: split-fp16 MFMA
- *       (hi*hi + hi*lo + lo*hi), fp32 accumulate -- fp32-class accuracy; |values| must stay below
- *       ~1.3e5 (they saturate beyond).  ev_* as in rmnet_memory_read_f32_ev (may be NULL).
+ *       (hi*hi + hi*lo + lo*hi), fp32 accumulate -- fp32-class accuracy.  ev_* as in
+ *       rmnet_memory_read_f32_ev (may be NULL).
+ * Range: K and V are stored times 2^6; elements with |x| >= 1023.5 saturate and NaN / Inf are lost.  Every
+ *       16-byte group written with such an element increments the int32 overflow word that lives at byte
+ *       rmnet_bank_overflow_offset() of the bank (the caller zero-fills a new bank); a caller that cannot
+ *       rule such inputs out checks it (once per clip is enough) and re-runs with
+ *       rmnet_memory_read_f32(..., RMNET_MR_EXACT_FP32).  Tcap <= 512.
  * ------------------------------------------------------------------------------------------- */
 size_t rmnet_bank_bytes(int no, int Tcap, int h, int w);
+size_t rmnet_bank_overflow_offset(int no, int Tcap, int h, int w);
 int rmnet_bank_append_f32(void *bank, int no, int Tcap, int h, int w, int slot, const float *k4,
                           const float *v4, const int32_t *rects, void *stream);
 size_t rmnet_bank_read_workspace_bytes(int no, int h, int w);

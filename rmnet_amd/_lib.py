@@ -42,6 +42,7 @@ SIGNATURES = {
         ctypes.c_longlong, c_f32p, c_f32p, c_i32p, c_i32p, ctypes.c_int, ctypes.c_void_p,
         ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'rmnet_bank_bytes': (ctypes.c_size_t, [ctypes.c_int] * 4),
+    'rmnet_bank_overflow_offset': (ctypes.c_size_t, [ctypes.c_int] * 4),
     'rmnet_bank_append_f32': (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p,
         c_f32p, c_i32p, ctypes.c_void_p]),

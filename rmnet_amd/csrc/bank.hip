@@ -45,6 +45,12 @@ constexpr int kQT = 64, kJT = 32;
 constexpr int kThreads = 256;
 constexpr int kMaxT = 512;
 constexpr float kDeferLog2 = 11.5415603f;   // 8 * log2(e): P <= e^8 stays far inside fp16 range (65504)
+// The S accumulators are in RAW units: keys are stored times 2^6 and the query fragments carry
+// log2(e) / sqrt(De) times 2^6 as well (both operands then sit where fp16's hi AND lo planes are
+// normal numbers), so S_log2 = kSraw * S_raw with kSraw = 2^-12; the factor rides in the soft-max's
+// fma (exp2(S_raw * kSraw - m)), it costs no instruction.
+constexpr float kSraw = 1.0f / 4096.0f;
+constexpr float kDeferRaw = kDeferLog2 * 4096.0f;
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -56,6 +62,17 @@ __device__ inline void split_f16(float x, _Float16& hi, _Float16& lo) {
   const float c = fminf(fmaxf(x, -65504.0f), 65504.0f);   // saturate instead of inf/NaN
   hi = (_Float16)c;
   lo = (_Float16)fminf(fmaxf(x - (float)hi, -65504.0f), 65504.0f);
+}
+// Keys and values are stored times 2^kBankShift (exact): fp16's window then covers |x| from
+// 65504 / 64 = 1023.5 down to an absolute error floor of 2^-25 / 64 = 4.7e-10 per element (the lo
+// plane is subnormal below |x| = 2^-3 / 64), which is where conv-net activations live; 1/64 is folded
+// back into the query scale (keys) and into the combine's normalisation (values).  An element beyond
+// +-1023.5 saturates and is COUNTED in the bank's overflow word (rmnet_bank_overflow_count).
+constexpr float kBankScale = 64.0f;      // 2^6
+__device__ inline bool split_scaled(float x, _Float16& hi, _Float16& lo) {
+  const float y = x * kBankScale;
+  split_f16(y, hi, lo);
+  return !(fabsf(y) <= 65504.0f);        // (also true for NaN)
 }
 
 // Reductions over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48) with the gfx950
@@ -96,27 +113,35 @@ BankView bank_view(void* base, int no, int Tcap, int h, int w) {
   b.vh = p; p += vplane;
   b.vl = p; p += vplane;
   b.area = reinterpret_cast<int32_t*>(p);
+  p += ((size_t)no * Tcap * 4 + 255) & ~(size_t)255;
+  b.ovf = reinterpret_cast<int32_t*>(p);
   return b;
 }
 
 size_t bank_bytes(int no, int Tcap, int h, int w) {
   const size_t hwp = ((size_t)h * w + kJT - 1) / kJT * kJT;
   return 2 * (size_t)no * Tcap * hwp * kDe * 2 + 2 * (size_t)no * Tcap * kDo * hwp * 2 +
-         (((size_t)no * Tcap * 4 + 255) & ~(size_t)255);
+         (((size_t)no * Tcap * 4 + 255) & ~(size_t)255) + 256;   // + the overflow word
 }
 
 namespace {
 
 // ------------------------------------------------------------------------------------------ append
-__global__ __launch_bounds__(kThreads) void bk_append(BankView b, int slot,
+// grid = (tiles, no * nf, 1 + kDo / kDe): blockIdx.y = o * nf + f writes slot slot0 + f of object o from
+// frame f of the source: element (o, c, f, cell) of k4 at o * k_os + c * k_cs + f * hw + cell (same for
+// v4).  The frame loop appends one frame of contiguous [no,C,h,w] tensors (nf = 1, k_cs = hw); the
+// drop-in MemoryReader entry stages all T frames of a [no,C,T,h,w] memory in one launch.
+__global__ __launch_bounds__(kThreads) void bk_append(BankView b, int slot0, int nf,
                                                       const float* __restrict__ k4,
-                                                      const float* __restrict__ v4,
+                                                      const float* __restrict__ v4, long long k_cs,
+                                                      long long k_os, long long v_cs, long long v_os,
                                                       const int32_t* __restrict__ rects) {
   __shared__ float tile[kJT][kDe + 1];
-  const int u = blockIdx.x, o = blockIdx.y, tid = threadIdx.x;
+  const int u = blockIdx.x, tid = threadIdx.x;
+  const int o = (int)blockIdx.y / nf, f = (int)blockIdx.y - o * nf, slot = slot0 + f;
   Rect rc{0, b.w - 1, 0, b.h - 1};
   if (rects) {
-    const int32_t* r = rects + (size_t)o * 4;
+    const int32_t* r = rects + (size_t)blockIdx.y * 4;
     rc = Rect{max(r[0], 0), min(r[1], b.w - 1), max(r[2], 0), min(r[3], b.h - 1)};
   }
   const int area = rc.area();
@@ -135,24 +160,26 @@ __global__ __launch_bounds__(kThreads) void bk_append(BankView b, int slot,
   // each (five short dependency chains instead of one long one: a launch has < 1 workgroup per CU)
   if (blockIdx.z == 0) {
     // keys: gather [c][cell] -> LDS [p][c] -> split -> [n][c]
-    const float* kb = k4 + (size_t)o * kDe * b.hw + cell;
+    const float* kb = k4 + (size_t)o * k_os + (size_t)f * b.hw + cell;
 #pragma unroll
     for (int i = 0; i < kDe / 8; ++i) {
       const int c = rg + 8 * i;
-      tile[p][c] = valid ? kb[(size_t)c * b.hw] : 0.0f;
+      tile[p][c] = valid ? kb[(size_t)c * k_cs] : 0.0f;
     }
     __syncthreads();
     {
       const int row = tid >> 3, c0 = (tid & 7) * 16;
       half8 h0, h1, l0, l1;
+      bool over = false;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         _Float16 hi, lo;
-        split_f16(tile[row][c0 + e], hi, lo);
+        over |= split_scaled(tile[row][c0 + e], hi, lo);
         h0[e] = hi; l0[e] = lo;
-        split_f16(tile[row][c0 + 8 + e], hi, lo);
+        over |= split_scaled(tile[row][c0 + 8 + e], hi, lo);
         h1[e] = hi; l1[e] = lo;
       }
+      if (over) atomicAdd(b.ovf, 1);
       const size_t off = ((so * b.hwp + (size_t)u * kJT + row) * kDe + c0) * sizeof(_Float16);
       *reinterpret_cast<half8*>(b.kh + off) = h0;
       *reinterpret_cast<half8*>(b.kh + off + 16) = h1;
@@ -167,7 +194,7 @@ __global__ __launch_bounds__(kThreads) void bk_append(BankView b, int slot,
   // {4gg..4gg+3, 16+4gg..16+4gg+3} (kperm) -- from 8 LDS reads and writes it with ONE
   // 16-byte store per plane; a wave covers 16 channels x 4 groups = 4 x 256 B runs.
   {
-    const float* vb = v4 + (size_t)o * kDo * b.hw + cell;
+    const float* vb = v4 + (size_t)o * v_os + (size_t)f * b.hw + cell;
     const size_t vbase = (so * (b.hwp / kJT) + u) * (size_t)(kDo * kJT) * sizeof(_Float16);
     const int gg = tid & 3;
     {
@@ -175,20 +202,22 @@ __global__ __launch_bounds__(kThreads) void bk_append(BankView b, int slot,
 #pragma unroll
       for (int i = 0; i < kDe / 8; ++i) {
         const int c = rg + 8 * i;
-        tile[p][c] = valid ? vb[(size_t)(c0 + c) * b.hw] : 0.0f;
+        tile[p][c] = valid ? vb[(size_t)(c0 + c) * v_cs] : 0.0f;
       }
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < kDe / 64; ++i) {
         const int dl = (tid >> 2) + 64 * i, d = c0 + dl;
         half8 hi8, lo8;
+        bool over = false;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int j = 4 * gg + (e & 3) + 16 * (e >> 2);
           _Float16 hi, lo;
-          split_f16(tile[j][dl], hi, lo);
+          over |= split_scaled(tile[j][dl], hi, lo);
           hi8[e] = hi; lo8[e] = lo;
         }
+        if (over) atomicAdd(b.ovf, 1);
         const size_t off = vbase + (size_t)(((d >> 4) * 64) + (d & 15) + 16 * gg) * 16;
         *reinterpret_cast<half8*>(b.vh + off) = hi8;
         *reinterpret_cast<half8*>(b.vl + off) = lo8;
@@ -206,9 +235,10 @@ struct BArgs {
   float* ws_ml;              // [no][slots][2][kQT]: running reference (log2 domain) and sum
   int32_t* ws_plan;          // [no][kPlanInts]
   int T;
+  int gate;                  // != 0: do nothing when the bank's overflow word is set (mr_main then runs instead)
   int obj0, nobj;            // objects [obj0, obj0 + nobj) belong to this launch (nobj <= kMaxObj)
   int slot0, target;         // first partial slot of the launch; workgroups to aim for
-  float qscale;              // log2(e) / sqrt(De), folded into the query fragments
+  float qscale;              // log2(e) / sqrt(De) * 2^6, folded into the query fragments
 };
 
 constexpr int kKbuf = kJT * kDe * 2;                       // bytes of one K plane tile (8 KB)
@@ -324,7 +354,8 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
     }
     const float* qb = a.qk + (size_t)o * kDe * b.hw + cell;
     // 1/sqrt(De) (models/rmnet.py:156) and log2(e) are folded into the query: S comes out of the
-    // MFMAs in the log2 domain and the soft-max is a bare v_exp_f32 (= 2^x) per element.
+    // MFMAs in the log2 domain (times 2^12, see kSraw) and the soft-max is one fma + v_exp_f32 (= 2^x)
+    // per element.
     const float keep = qvalid ? a.qscale : 0.0f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
@@ -389,15 +420,16 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
     float tmax = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])),
                        fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
     tmax = group4_max(tmax);
-    // deferred running reference (first tile: mref = -inf): bump only when exceeded by > kDefer
-    const bool bump = tmax > mref + kDeferLog2;
-    const float alpha = bump ? __builtin_amdgcn_exp2f(mref - tmax) : 1.0f;
+    // deferred running reference (raw units; first tile: mref = -inf): bump only when exceeded by > kDefer
+    const bool bump = tmax > mref + kDeferRaw;
+    const float alpha = bump ? __builtin_amdgcn_exp2f((mref - tmax) * kSraw) : 1.0f;
     mref = bump ? tmax : mref;
+    const float nm = -mref * kSraw;
     float pv[8];
     float rs = 0.0f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      pv[e] = __builtin_amdgcn_exp2f(sv[e] - mref);   // in [0, e^8]: no saturation needed for the split
+      pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[e], kSraw, nm));   // in [0, e^8]: no saturation needed for the split
       rs += pv[e];
     }
     rs = group4_sum(rs);
@@ -460,7 +492,7 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
   }
   if (g == 0 && !(BK_ABLATE & 8)) {
     float* wm = a.ws_ml + (size_t)wk.slot * 2 * kQT;
-    wm[wave * 16 + l15] = mref;
+    wm[wave * 16 + l15] = mref * kSraw;                // log2 domain for the combine
     wm[kQT + wave * 16 + l15] = lsum;
   }
   BK_STAMP();
@@ -651,6 +683,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool producer = wave < kProducers;
+  if (a.gate && __builtin_amdgcn_readfirstlane(*b.ovf) != 0) return;   // out-of-window element: exact fp32 path runs
   if (producer && BK_PRIO > 0) __builtin_amdgcn_s_setprio(BK_PRIO);
 
   // ---- launch-wide plan, computed identically by every workgroup from the device-resident boxes
@@ -820,13 +853,24 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
 
 int launch_bank_append(void* bank, int no, int Tcap, int h, int w, int slot, const float* k4,
                        const float* v4, const int32_t* rects, hipStream_t st) {
-  if (!bank || !k4 || !v4 || no <= 0 || Tcap <= 0 || h <= 0 || w <= 0 || slot < 0 || slot >= Tcap)
+  const long long hw = (long long)h * w;
+  return launch_bank_stage(bank, no, Tcap, h, w, slot, 1, k4, v4, hw, hw * kDe, hw, hw * kDo, rects, st);
+}
+
+int launch_bank_stage(void* bank, int no, int Tcap, int h, int w, int slot0, int nf, const float* k4,
+                      const float* v4, long long k_cs, long long k_os, long long v_cs, long long v_os,
+                      const int32_t* rects, hipStream_t st) {
+  if (!bank || !k4 || !v4 || no <= 0 || Tcap <= 0 || h <= 0 || w <= 0 || nf <= 0 || slot0 < 0 ||
+      slot0 + nf > Tcap)
     return RMNET_E_INVALID_ARG;
-  if (no > 65535 || Tcap > kMaxT) return RMNET_E_UNSUPPORTED;
+  if ((long long)no * nf > 65535 || Tcap > kMaxT) return RMNET_E_UNSUPPORTED;
   const BankView b = bank_view(bank, no, Tcap, h, w);
-  hipLaunchKernelGGL(bk_append, dim3(b.hwp / kJT, no, 1 + kDo / kDe), dim3(kThreads), 0, st, b, slot, k4, v4, rects);
+  hipLaunchKernelGGL(bk_append, dim3(b.hwp / kJT, no * nf, 1 + kDo / kDe), dim3(kThreads), 0, st, b, slot0, nf,
+                     k4, v4, k_cs, k_os, v_cs, v_os, rects);
   return check_launch();
 }
+
+size_t bank_overflow_offset(int no, int Tcap, int h, int w) { return bank_bytes(no, Tcap, h, w) - 256; }
 
 int launch_bank_main(const BankReadArgs& m, hipStream_t st) {
   BArgs a;
@@ -834,7 +878,8 @@ int launch_bank_main(const BankReadArgs& m, hipStream_t st) {
   a.qk = m.qk; a.qv = m.qv; a.qry_rects = m.qry_rects;
   a.ws_o = m.ws_o; a.ws_ml = m.ws_ml; a.ws_plan = m.ws_plan;
   a.T = m.T;
-  a.qscale = 1.44269504088896341f / sqrtf((float)kDe);
+  a.gate = m.gate;
+  a.qscale = 1.44269504088896341f / sqrtf((float)kDe) * kBankScale;   // (the un-scaling is kSraw in the soft-max)
   // Objects are planned together in groups of <= kMaxObj; a group's partial slots start at
   // bank_group_slot0() and hold at most target + nobj * (query tiles) segments.
   for (int obj0 = 0; obj0 < m.no; obj0 += kMaxObj) {

@@ -82,6 +82,11 @@ size_t rmnet_bank_bytes(int no, int Tcap, int h, int w) {
   return bank_bytes(no, Tcap, h, w);
 }
 
+size_t rmnet_bank_overflow_offset(int no, int Tcap, int h, int w) {
+  if (no <= 0 || Tcap <= 0 || h <= 0 || w <= 0) return 0;
+  return bank_overflow_offset(no, Tcap, h, w);
+}
+
 int rmnet_bank_append_f32(void* bank, int no, int Tcap, int h, int w, int slot, const float* k4,
                           const float* v4, const int32_t* rects, void* stream) {
   return launch_bank_append(bank, no, Tcap, h, w, slot, k4, v4, rects, static_cast<hipStream_t>(stream));

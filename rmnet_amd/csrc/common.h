@@ -112,10 +112,12 @@ struct BankView {
   char *kh, *kl;   // [no][Tcap][hwp][128] fp16 hi / lo  (cell-major keys)
   char *vh, *vl;   // [no][Tcap][512][hwp] fp16 hi / lo  (channel-major values, cells permuted per 32)
   int32_t* area;   // [no][Tcap] cells inside the box of each memorised frame
+  int32_t* ovf;    // number of 16-byte groups written so far that held an element outside fp16's window
   int no, Tcap, h, w, hw, hwp;
 };
 BankView bank_view(void* base, int no, int Tcap, int h, int w);
 size_t bank_bytes(int no, int Tcap, int h, int w);
+constexpr float kBankValueUnscale = 1.0f / 64.0f;   // values are stored times 2^6 (bank.hip)
 
 // Split heuristic shared by the read kernels and the combine kernel (must agree exactly).
 #ifndef RMNET_SPLIT_TARGET
@@ -203,9 +205,14 @@ struct BankReadArgs {
   void* ws;
   size_t ws_bytes;
   hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_end = nullptr;
+  int gate = 0;               // != 0: bk_main returns at once when the bank's overflow word is set
 };
 int launch_bank_append(void* bank, int no, int Tcap, int h, int w, int slot, const float* k4,
                        const float* v4, const int32_t* rects, hipStream_t st);
+int launch_bank_stage(void* bank, int no, int Tcap, int h, int w, int slot0, int nf, const float* k4,
+                      const float* v4, long long k_cs, long long k_os, long long v_cs, long long v_os,
+                      const int32_t* rects, hipStream_t st);   // nf frames of a strided [no,C,T,h,w] source
+size_t bank_overflow_offset(int no, int Tcap, int h, int w);
 int launch_bank_main(const BankReadArgs& a, hipStream_t st);   // bank.hip: the read kernel only
 size_t bank_read_ws_bytes(int no, int h, int w);
 int launch_bank_read(BankReadArgs& a, hipStream_t st);         // memory_read.hip: main + combine

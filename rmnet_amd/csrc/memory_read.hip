@@ -74,6 +74,8 @@ struct KArgs {
   float sqrt_de;
   const int32_t* bank_area;  // non-null: memory side comes from a bank (areas [no][bank_tcap])
   int bank_tcap;
+  const int32_t* gate;       // non-null: the overflow word of a transient bank (drop-in entry): mr_main runs
+                             // only when it is set, and the combine then reads mr_main's (natural-log) partials
 };
 
 struct Plan {
@@ -190,6 +192,7 @@ __global__ __launch_bounds__(kThreads, 1) void mr_main(const KArgs a) {
 
   const int tid = threadIdx.x, o = blockIdx.y;
   const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+  if (a.gate && __builtin_amdgcn_readfirstlane(*a.gate) == 0) return;   // the split-fp16 bank path did the read
   if (tid < 2) flags[tid] = 0;
   const Plan pl = make_plan<REGIONAL>(a, o, prefix);
   const int nact = pl.nqt * pl.nsplit;
@@ -406,7 +409,8 @@ __global__ __launch_bounds__(kThreads, kCombCh == 16 ? 6 : 5) void mr_combine(co
     }
     return r;
   };
-  const bool log2d = a.bank_area != nullptr;
+  const bool log2d = a.bank_area != nullptr && !(a.gate && __builtin_amdgcn_readfirstlane(*a.gate) != 0);
+  const float vun = log2d ? kBankValueUnscale : 1.0f;   // the bank stores values times 2^6
   const int qi = tid & 63, sl = tid >> 6;
   const float n_out = (float)(a.T * a.hw - pl.M);
   const float* __restrict__ ml = a.ws_ml;
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(kThreads, kCombCh == 16 ? 6 : 5) void mr_combine(co
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) ltot += __shfl_xor(ltot, d);
     if (n_out > 0.0f) ltot += n_out * ex(-mtot);
-    Wm[tid] = wgt / ltot;
+    Wm[tid] = wgt / ltot * vun;
   }
   __syncthreads();                                                         // barrier 1
 
@@ -556,7 +560,7 @@ __global__ __launch_bounds__(kThreads, kCombCh == 16 ? 6 : 5) void mr_combine(co
 
   {  // accumulate: thread = (query tile it = sl, lane qi) of the channel tiles of this block
     const int q = sl * 16 + (qi & 15), gg = qi >> 4;
-    const float inv = 1.0f / (red2[0][q] + red2[1][q] + red2[2][q] + red2[3][q]);
+    const float inv = vun / (red2[0][q] + red2[1][q] + red2[2][q] + red2[3][q]);
     f32x4 acc[kCombDt];
 #pragma unroll
     for (int k = 0; k < kCombDt; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -746,14 +750,21 @@ inline int slots_for(int no, int hw) {
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// Partial slots of the drop-in entry's workspace: enough for mr_main's per-object grid AND for bk_main's
+// launch-wide chunks (the two share one partial area; only one of them writes it in a given call).
+inline size_t mr_slots(int no, int hw) {
+  const size_t a = (size_t)no * slots_for(no, hw), b = (size_t)bank_total_slots(no, hw);
+  return a > b ? a : b;
+}
+
 }  // namespace
 
 size_t memory_read_ws_bytes(int no, int De, int Do, int T, int h, int w, int flags) {
   const size_t hw = (size_t)h * w;
   if (fast_shape(De, Do, T, flags)) {
-    const size_t slots = slots_for(no, (int)hw);
-    return align256((size_t)no * slots * kDo * kQT * 4) + align256((size_t)no * slots * 2 * kQT * 4) +
-           align256((size_t)no * kPlanInts * 4);
+    const size_t slots = mr_slots(no, (int)hw);
+    return align256(slots * kDo * kQT * 4) + align256(slots * 2 * kQT * 4) + align256((size_t)no * kPlanInts * 4) +
+           ((flags & RMNET_MR_EXACT_FP32) ? 0 : align256(bank_bytes(no, T, h, w)));   // + the transient bank
   }
   return align256((size_t)no * T * hw * hw * 4);  // a p-sized buffer
 }
@@ -775,6 +786,13 @@ int launch_memory_read(const MemReadArgs& m, hipStream_t st) {
   if (fast) {
     if (!m.ws || m.ws_bytes < memory_read_ws_bytes(m.no, m.De, m.Do, m.T, m.h, m.w, m.flags))
       return RMNET_E_WORKSPACE;
+    // Default: stage the memory into a TRANSIENT split-fp16 bank (one launch over all T frames, same
+    // bytes as the fp32 source) and run the bank read -- 3-4x faster than the exact-fp32 MFMA kernel
+    // even with the staging pass.  The staging kernel counts elements outside fp16's window; if there
+    // are any, bk_main returns at once and mr_main (exact fp32, no range limit) does the read instead --
+    // decided on the device, no host sync.  RMNET_MR_EXACT_FP32 forces mr_main.
+    const bool via_bank = !(m.flags & RMNET_MR_EXACT_FP32) && (long long)m.no * m.T <= 65535;
+    const size_t nslots = mr_slots(m.no, (int)hw);
     KArgs a;
     a.mk = m.mk; a.mv = m.mv; a.qk = m.qk; a.qv = m.qv; a.out = m.out;
     a.mem_rects = m.mem_rects; a.qry_rects = m.qry_rects;
@@ -782,17 +800,32 @@ int launch_memory_read(const MemReadArgs& m, hipStream_t st) {
     a.mk_cs = mk_cs; a.mk_os = mk_os; a.mv_cs = mv_cs; a.mv_os = mv_os;
     a.slots = slots_for(m.no, (int)hw);
     a.sqrt_de = sqrt_de;
-    a.bank_area = nullptr; a.bank_tcap = 0;
+    a.bank_area = nullptr; a.bank_tcap = 0; a.gate = nullptr;
     a.ws_o = static_cast<float*>(m.ws);
-    a.ws_ml = reinterpret_cast<float*>(static_cast<char*>(m.ws) +
-                                       align256((size_t)m.no * a.slots * kDo * kQT * 4));
-    a.ws_plan = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.ws_ml) +
-                                           align256((size_t)m.no * a.slots * 2 * kQT * 4));
+    a.ws_ml = reinterpret_cast<float*>(static_cast<char*>(m.ws) + align256(nslots * kDo * kQT * 4));
+    a.ws_plan = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.ws_ml) + align256(nslots * 2 * kQT * 4));
+    char* bank = reinterpret_cast<char*>(a.ws_plan) + align256((size_t)m.no * kPlanInts * 4);
+    if (via_bank) {
+      const BankView b = bank_view(bank, m.no, m.T, m.h, m.w);
+      if (hipMemsetAsync(b.ovf, 0, sizeof(int32_t), st) != hipSuccess) return RMNET_E_LAUNCH;
+      if (int e = launch_bank_stage(bank, m.no, m.T, m.h, m.w, 0, m.T, m.mk, m.mv, mk_cs, mk_os, mv_cs, mv_os,
+                                    m.mem_rects, st))
+        return e;
+      a.bank_area = b.area; a.bank_tcap = m.T; a.gate = b.ovf;
+    }
     const int nqt_max = (int)((hw + 1 + kQT - 1) / kQT);
     dim3 g1(a.slots, m.no);
     const int cch = comb_channels(m.no);
     dim3 g2((unsigned)(nqt_max + (regional ? (hw + kQT - 1) / kQT : 0)), kDo / cch, m.no);
     if (m.ev_start && hipEventRecord(m.ev_start, st) != hipSuccess) return RMNET_E_LAUNCH;
+    if (via_bank) {
+      BankReadArgs r;
+      r.bank = bank; r.no = m.no; r.Tcap = m.T; r.h = m.h; r.w = m.w; r.T = m.T;
+      r.qk = m.qk; r.qv = m.qv; r.qry_rects = m.qry_rects; r.out = m.out;
+      r.ws_o = a.ws_o; r.ws_ml = a.ws_ml; r.ws_plan = a.ws_plan; r.slots = (int)nslots;
+      r.ws = nullptr; r.ws_bytes = 0; r.gate = 1;
+      if (int e = launch_bank_main(r, st)) return e;
+    }
     if (regional)
       hipLaunchKernelGGL(mr_main<true>, g1, dim3(kThreads), 0, st, a);
     else
@@ -863,7 +896,7 @@ int launch_bank_read(BankReadArgs& m, hipStream_t st) {
   a.no = m.no; a.T = m.T; a.h = m.h; a.w = m.w; a.hw = hw;
   a.mk_cs = a.mk_os = a.mv_cs = a.mv_os = 0;
   a.slots = m.slots; a.sqrt_de = 0.0f;
-  a.bank_area = b.area; a.bank_tcap = m.Tcap;
+  a.bank_area = b.area; a.bank_tcap = m.Tcap; a.gate = nullptr;
   a.ws_o = m.ws_o; a.ws_ml = m.ws_ml; a.ws_plan = m.ws_plan;
   const int nqt_max = (hw + 1 + kQT - 1) / kQT;
   const bool qreg = m.qry_rects != nullptr;

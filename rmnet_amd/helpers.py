@@ -25,7 +25,7 @@ def pad_divide_by(in_list, d, in_size):
 def var_or_cuda(x, device=None):
     """utils/helpers.py:16-24: contiguous + move to the GPU unless ``device`` is the CPU."""
     x = x.contiguous()
-    if torch.cuda.is_available() and device != torch.device('cpu'):
+    if torch.cuda.is_available() and (device is None or torch.device(device).type != 'cpu'):
         x = x.cuda(non_blocking=True) if device is None else x.cuda(device=device, non_blocking=True)
     return x
 
@@ -33,6 +33,10 @@ def var_or_cuda(x, device=None):
 def multi_scale_inference(cfg, tflownet, rmnet, frames, masks, n_objects):
     """utils/helpers.py:44-78.  ``cfg.TEST`` needs FRAME_SCALES, FLIP_LR, MEMORIZE_EVERY."""
     _, n, c, h, w = frames.shape
+    # the reference's networks are DataParallel-wrapped, which moves the loader's host tensors to the GPU
+    # (core/inference.py:35-37); here the inputs are moved once, up front
+    dev = next(rmnet.parameters()).device
+    frames, masks = var_or_cuda(frames, dev), var_or_cuda(masks, dev)
     est_flows, est_probs = [], []
     for fs in cfg.TEST.FRAME_SCALES:
         fr = F.interpolate(frames[0], scale_factor=fs, mode='bilinear', align_corners=False).unsqueeze(0)

@@ -356,6 +356,16 @@ def fuse_epilogues_(module, enable=True):
         else:
             m.register_buffer(name, t, persistent=False)
 
+    if enable and any(isinstance(m, _Identity) for m in module.modules()):
+        raise RuntimeError('fuse_epilogues() after fuse_for_inference(): the BatchNorms are already folded into '
+                           'the convolutions -- use one or the other')
+    if enable and not getattr(module, '_fuse_hook', None):
+        # the (scale, shift) pairs and the 5-channel stem are SNAPSHOTS of the parameters: refresh them
+        # whenever a checkpoint is loaded afterwards, so that stale statistics can never be used
+        def _refresh(mod, incompatible):
+            if any(getattr(m, '_fused', False) for m in mod.modules()):
+                fuse_epilogues_(mod, True)
+        module._fuse_hook = module.register_load_state_dict_post_hook(_refresh)
     for m in module.modules():
         if isinstance(m, _Bottleneck):
             for i, bn in ((1, m.bn1), (2, m.bn2), (3, m.bn3)):

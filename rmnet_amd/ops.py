@@ -15,6 +15,11 @@ import torch
 from . import _lib
 
 
+MR_FORCE_GENERIC = 1     # include/rmnet_hip.h RMNET_MR_*
+MR_EXACT_FP32 = 2
+BANK_MAX_SLOTS = 512     # csrc/bank.hip kMaxT
+
+
 def _check(t, name, dtype=torch.float32):
     if not isinstance(t, torch.Tensor):
         raise RuntimeError('%s must be a torch.Tensor' % name)
@@ -200,6 +205,13 @@ class MemoryBank:
         off = 2 * self.no * self.capacity * hwp * 128 * 2 + 2 * self.no * self.capacity * 512 * hwp * 2
         return self.blob[off:off + self.no * self.capacity * 4].view(torch.int32).view(self.no, self.capacity)
 
+    def overflow_count(self):
+        """Number of 16-byte groups appended so far that held an element outside the bank's fp16
+        window (|x| >= 1023.5, NaN, Inf; include/rmnet_hip.h).  Synchronises the stream -- call it once
+        per clip, not per frame.  Non-zero = the read-outs of this bank are not trustworthy."""
+        off = _lib.load().rmnet_bank_overflow_offset(self.no, self.capacity, self.h, self.w)
+        return int(self.blob[off:off + 4].view(torch.int32).item())
+
     def stage(self, k4, v4, rects):
         """Write one frame into the first free slot without committing it (the tentative previous
         frame of models/rmnet.py:416-426).  Returns the number of frames visible to ``read``."""
@@ -231,6 +243,52 @@ class MemoryBank:
                                          _ptr(q_key), _ptr(q_val), _ptr(qry_rects), _ptr(out), _ptr(ws),
                                          ws.numel(), _stream(self.device), ev[0], ev[1], ev[2])
         _lib.check(rc, 'rmnet_bank_read_f32')
+        return out
+
+
+class TensorBank:
+    """Same interface as ``MemoryBank`` on plain fp32 tensors in the reference's layout
+    ([no,C,Tcap,h,w] + cell rectangles), read with the exact-fp32 kernel: no limit on the number of
+    slots, no limit on the value range, about 4x slower.  The frame loop switches to it for clips with
+    more than 512 memorised frames and when a ``MemoryBank`` reported out-of-window values."""
+
+    def __init__(self, no, capacity, h, w, device):
+        self.no, self.capacity, self.h, self.w = int(no), int(capacity), int(h), int(w)
+        self.device = torch.device(device)
+        with torch.cuda.device(self.device):
+            self.m_key = torch.zeros(self.no, 128, self.capacity, self.h, self.w, device=self.device)
+            self.m_val = torch.zeros(self.no, 512, self.capacity, self.h, self.w, device=self.device)
+            self.rects = torch.zeros(self.no, self.capacity, 4, dtype=torch.int32, device=self.device)
+        self.committed = 0
+
+    def append(self, slot, k4, v4, rects=None):
+        _check(k4, 'k4')
+        _check(v4, 'v4')
+        self.m_key[:, :, slot] = k4
+        self.m_val[:, :, slot] = v4
+        if rects is None:
+            self.rects[:, slot] = torch.tensor([0, self.w - 1, 0, self.h - 1], dtype=torch.int32, device=self.device)
+        else:
+            self.rects[:, slot] = rects.view(self.no, 4)
+
+    def overflow_count(self):
+        return 0
+
+    def stage(self, k4, v4, rects):
+        if self.committed >= self.capacity:
+            raise RuntimeError('memory bank overflow (%d slots)' % self.capacity)
+        self.append(self.committed, k4, v4, rects)
+        return self.committed + 1
+
+    def commit(self):
+        self.committed += 1
+
+    def read(self, T, q_key, q_val, qry_rects=None, out=None, events=None, ws=None):
+        if qry_rects is None:
+            qry_rects = torch.tensor([[0, self.w - 1, 0, self.h - 1]] * self.no, dtype=torch.int32, device=self.device)
+        out, _ = memory_read(self.m_key, self.m_val, q_key, q_val, self.rects[:, :T].contiguous(),
+                             qry_rects.contiguous(), T=T, out=out, events=events,
+                             flags=MR_EXACT_FP32 if T <= BANK_MAX_SLOTS else MR_FORCE_GENERIC)
         return out
 
 

@@ -57,6 +57,11 @@ class MemoryReader(nn.Module):
 
 
 class RMNet(nn.Module):
+    """INFERENCE ONLY.  The memory read, the bank, the box masking and the fused decoder tail are raw
+    HIP kernels without autograd: ``forward`` / ``frame_step`` / ``segment`` / ``memorize`` run under
+    ``torch.no_grad()`` and refuse to run in training mode (the reference's training path -- losses,
+    DataParallel, models/rmnet.py's ``self.training`` branches -- is out of scope)."""
+
     def __init__(self, cfg=None):
         super().__init__()
         self.cfg = cfg
@@ -147,6 +152,10 @@ class RMNet(nn.Module):
         expt = prev_mask if flow is None else self.warp(prev_mask, flow)[0]
         return self.att_map_generator(expt.contiguous())
 
+    def _inference_only(self):
+        if self.training:
+            raise RuntimeError('rmnet_amd.RMNet is inference-only (its HIP kernels have no autograd): call .eval()')
+
     def _encode_memory(self, frame, masks, n_objects):
         """EncoderMemory + KeyValue for every object in flight, and the boxes of the (padded)
         masks as pixel boxes + cell rectangles.  K/V are returned UN-masked."""
@@ -174,9 +183,11 @@ class RMNet(nn.Module):
         _, bboxes, rects = ops.region_map(masks.contiguous(), want_map=False, cell_grid=(0, 0, 16, h, w))
         return k4, v4, bboxes, rects
 
+    @torch.no_grad()
     def memorize(self, frame, masks, n_objects):
         """models/rmnet.py:207-250 with the reference's return values:
         (k4 [B,K,128,1,h,w], v4 [B,K,512,1,h,w], bboxes [B,K,4]), K/V box-masked."""
+        self._inference_only()
         B, K = masks.shape[:2]
         k4, v4, bboxes, rects = self._encode_memory(frame, masks, n_objects)
         k4, v4 = self.pad_memory([k4, v4], n_objects, K)
@@ -212,7 +223,7 @@ class RMNet(nn.Module):
             k4e, v4e = k4.index_select(0, batch_of_obj), v4.index_select(0, batch_of_obj)
             r3e, r2e = r3.index_select(0, batch_of_obj), r2.index_select(0, batch_of_obj)
         ev = getattr(self, '_profile_events', None)
-        if isinstance(m_key, ops.MemoryBank):       # the frame loop: pre-compacted split-fp16 bank
+        if isinstance(m_key, (ops.MemoryBank, ops.TensorBank)):   # the frame loop: pre-compacted split-fp16 bank
             m4 = m_key.read(T, k4e.contiguous(), v4e.contiguous(), qry_rects, events=ev)
         else:                                       # reference-layout fp32 tensors (public segment())
             m4, _ = ops.memory_read(m_key, m_val, k4e.contiguous(), v4e.contiguous(), mem_rects, qry_rects,
@@ -224,10 +235,12 @@ class RMNet(nn.Module):
         lw, uw, lh, uh = pad
         return logit[:, :, lh:logit.shape[2] - uh, lw:logit.shape[3] - uw]
 
+    @torch.no_grad()
     def segment(self, frame, att_map, keys, values, prev_bboxes, curr_bbox, n_objects):
         """models/rmnet.py:304-383, same arguments.  ``att_map`` is implied by ``curr_bbox`` (it is
         the box map of those boxes) and the memory masking by ``prev_bboxes`` [B,K,T,4]; keys/values
         [B,K,C,T,h,w] may be masked (as ``memorize`` returns them) or not."""
+        self._inference_only()
         B, K, _, T, h, w = keys.shape
         H, W = frame.shape[2:]
         lw, _, lh, _ = pad_amounts(H, W, 16)
@@ -257,15 +270,20 @@ class RMNet(nn.Module):
                 begin.append(begin[-1] + n)
             self.obj_begin = torch.tensor(begin, dtype=torch.int32, device=device)
 
-    def new_bank(self, ctx, capacity):
-        """Pre-allocated regional memory for one clip (replaces models/rmnet.py:191-205, 416-426)."""
-        return ops.MemoryBank(len(ctx.flat), capacity, ctx.h, ctx.w, ctx.device)
+    def new_bank(self, ctx, capacity, exact=False):
+        """Pre-allocated regional memory for one clip (replaces models/rmnet.py:191-205, 416-426): the
+        split-fp16 ``MemoryBank``, or -- for more than 512 memorised frames, or ``exact`` -- plain fp32
+        tensors read by the exact-fp32 kernel (``TensorBank``)."""
+        cls = ops.TensorBank if exact or capacity > ops.BANK_MAX_SLOTS else ops.MemoryBank
+        return cls(len(ctx.flat), capacity, ctx.h, ctx.w, ctx.device)
 
+    @torch.no_grad()
     def frame_step(self, ctx, bank, prev_frame, prev_mask, cur_frame, cur_flow, commit):
         """One iteration of models/rmnet.py:410-433: memorise frame t-1 (tentatively, or for good
         when ``commit``), derive the regional query boxes from the flow-warped previous mask, segment
         frame t.  Returns the logits [B,K,H,W] -- or, after ``fuse_epilogues()``, the pair
         (logits, soft-max over K of the logits).  No host synchronisation."""
+        self._inference_only()
         B, K = ctx.B, ctx.K
         k4, v4, boxes, rects = self._encode_memory(prev_frame, prev_mask, ctx.n_max)
         T = bank.stage(k4.contiguous(), v4.contiguous(), rects.view(B * K, 4).index_select(0, ctx.flat))
@@ -282,10 +300,12 @@ class RMNet(nn.Module):
         return self._segment_core(cur_frame, q_rects, bank, None, None, T, ctx.n_max, K, ctx.batch_of_obj,
                                   obj_begin=ctx.obj_begin)
 
-    def forward(self, frames, masks, optical_flows, n_objects, memorize_every, device=None):
+    @torch.no_grad()
+    def forward(self, frames, masks, optical_flows, n_objects, memorize_every, device=None, _exact=False):
         """models/rmnet.py:385-452.  frames [B,N,3,H,W] f32, masks [B,N,K,H,W] (one-hot, any int or
         float dtype), optical_flows [B,N,2,H,W] f32, n_objects [B,N] int -> est_masks [B,N,K,H,W]
         f32 on the GPU (the reference returns them on the host unless several GPUs are visible)."""
+        self._inference_only()
         dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         frames = frames.to(dev, non_blocking=True)
         optical_flows = optical_flows.to(dev, non_blocking=True)
@@ -302,7 +322,7 @@ class RMNet(nn.Module):
         fresh = {j for j in range(1, N) if bool((n_obj_host[:, j] != n_obj_host[:, j - 1]).any())}
         commit = set(range(0, N, memorize_every)) | fresh
         ctx = self._ClipContext(self, B, K, H, W, n_max, dev)
-        bank = self.new_bank(ctx, sum(1 for j in commit if j <= N - 2) + 1)
+        bank = self.new_bank(ctx, sum(1 for j in commit if j <= N - 2) + 1, exact=_exact)
 
         for t in range(1, N):
             logit = self.frame_step(ctx, bank, frames[:, t - 1], est[:, t - 1], frames[:, t],
@@ -323,4 +343,6 @@ class RMNet(nn.Module):
                     logit[b, missing] = _ABSENT_LOGIT
                     prob = None
             est[:, t] = F.softmax(logit, dim=1) if prob is None else prob
+        if bank.overflow_count():   # (one host sync per clip) K/V outside the split-fp16 window: redo the clip exactly
+            return self.forward(frames, masks, optical_flows, n_objects, memorize_every, device=dev, _exact=True)
         return est

@@ -106,6 +106,8 @@ class TinyFlowNet(nn.Module):
         return self
 
     def forward(self, frames, device=None):
+        # (the reference's DataParallel wrapper moves host frames to the GPU, core/inference.py:35-37)
+        frames = frames.to(self.conv1[0].weight.device, non_blocking=True)
         b, n, _, h, w = frames.shape
         flows = frames.new_zeros(b, n, 2, h, w)
         for t in range(1, n):

@@ -133,11 +133,15 @@ def _mr(g, name, **kw):
 
 def test_memory_read_golden_dense(golden_dir):
     g = np.load(os.path.join(golden_dir, 'memory_reader.npz'))
+    from rmnet_amd import ops
     for name in ['dense', 'regional', 'allmasked_query', 'peaky']:
-        out, p = _mr(g, name)
+        out, p = _mr(g, name)                      # default: transient split-fp16 bank inside the call
         assert p is None
         np.testing.assert_allclose(out.cpu().numpy(), g[name + '.mem_val'], atol=MR_ATOL, rtol=MR_RTOL,
                                    err_msg=name)
+        out_x, _ = _mr(g, name, flags=ops.MR_EXACT_FP32)   # exact-fp32 MFMA kernel (mr_main)
+        np.testing.assert_allclose(out_x.cpu().numpy(), g[name + '.mem_val'], atol=MR_ATOL, rtol=MR_RTOL,
+                                   err_msg=name + ' exact')
         out_g, _ = _mr(g, name, flags=1)          # generic kernels, same answer
         np.testing.assert_allclose(out_g.cpu().numpy(), g[name + '.mem_val'], atol=MR_ATOL, rtol=MR_RTOL)
 
@@ -200,13 +204,14 @@ def test_memory_read_random_vs_oracle(no, T, h, w, regional, oracle_mod):
     from rmnet_amd import ops
     rng = np.random.RandomState(no * 1000 + T * 100 + h)
     mk, mv, qk, qv, mr, qr = _random_case(rng, no, T, h, w, regional=regional)
-    if regional:
-        want, _ = oracle_mod.regional_memory_read(mk, mv, qk, qv, mr, qr)
-        got, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), cu(mr), cu(qr))
-    else:
-        want, _ = oracle_mod.memory_read(mk, mv, qk, qv)
-        got, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv))
-    np.testing.assert_allclose(got.cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL)
+    for flags in (0, ops.MR_EXACT_FP32):
+        if regional:
+            want, _ = oracle_mod.regional_memory_read(mk, mv, qk, qv, mr, qr)
+            got, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), cu(mr), cu(qr), flags=flags)
+        else:
+            want, _ = oracle_mod.memory_read(mk, mv, qk, qv)
+            got, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), flags=flags)
+        np.testing.assert_allclose(got.cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL)
 
 
 def test_memory_read_edge_rectangles(oracle_mod):
@@ -225,8 +230,9 @@ def test_memory_read_edge_rectangles(oracle_mod):
         clamp = lambda r: (max(r[0], 0), min(r[1], w - 1), max(r[2], 0), min(r[3], h - 1))
         want, _ = oracle_mod.regional_memory_read(mk, mv, qk, qv, np.array([[clamp(r) for r in mrect]], np.int32),
                                                   np.array([clamp(qrect)], np.int32))
-        got, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), cu(mr), cu(qr))
-        np.testing.assert_allclose(got.cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL, err_msg=str((mrect, qrect)))
+        for flags in (0, ops.MR_EXACT_FP32):
+            got, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), cu(mr), cu(qr), flags=flags)
+            np.testing.assert_allclose(got.cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL, err_msg=str((mrect, qrect)))
 
 
 def test_memory_read_bank_strides_and_running_max(oracle_mod):
@@ -240,11 +246,12 @@ def test_memory_read_bank_strides_and_running_max(oracle_mod):
     mr[:, 2] = (0, w - 1, 0, h - 1)
     qr[:] = (0, w - 1, 0, h - 1)
     want, _ = oracle_mod.regional_memory_read(mk[:, :, :T], mv[:, :, :T], qk, qv, mr[:, :T], qr)
-    got, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), cu(mr[:, :T]), cu(qr), T=T)
-    np.testing.assert_allclose(got.cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL)
     want_d, _ = oracle_mod.memory_read(mk[:, :, :T], mv[:, :, :T], qk, qv)
-    got_d, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), T=T)
-    np.testing.assert_allclose(got_d.cpu().numpy(), want_d, atol=MR_ATOL, rtol=MR_RTOL)
+    for flags in (0, ops.MR_EXACT_FP32):
+        got, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), cu(mr[:, :T]), cu(qr), T=T, flags=flags)
+        np.testing.assert_allclose(got.cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL)
+        got_d, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), T=T, flags=flags)
+        np.testing.assert_allclose(got_d.cpu().numpy(), want_d, atol=MR_ATOL, rtol=MR_RTOL)
 
 
 @pytest.mark.parametrize('no,T,h,w', [(1, 5, 30, 54), (3, 20, 45, 80)])
@@ -296,7 +303,9 @@ def _fill_bank(ops, mk, mv, mr, capacity=None):
     (1, 4, 8, 8, True), (1, 7, 16, 24, False), (2, 9, 10, 7, True),
     (14, 2, 6, 9, True),      # > 12 objects: the launch plan's LDS-atomic path
     (70, 1, 4, 5, True),      # > 64 objects: two launch groups
-    (5, 3, 30, 54, True)])    # boxes of very different sizes planned together
+    (5, 3, 30, 54, True),     # boxes of very different sizes planned together
+    (5, 5, 30, 54, True),     # BASELINE configs[2] at its exact shape: 5 objects, T = 5, 480p grid
+    (1, 3, 30, 54, True)])    # BASELINE configs[0]: 1 object, 3 memory frames
 def test_bank_read_vs_oracle(no, T, h, w, regional, oracle_mod):
     """The split-fp16 bank path (what the frame loop uses) against the oracle, same tolerance as the
     fp32-MFMA path."""
@@ -361,8 +370,10 @@ def test_bank_full_size_agrees_with_fp32_kernel(no, T, h, w):
     for t in range(T):
         bank.append(t, mk[:, :, t].contiguous(), mv[:, :, t].contiguous(), cu(mr[:, t]))
     got = bank.read(T, qk, qv, cu(qr))
-    want, _ = ops.memory_read(mk, mv, qk, qv, cu(mr), cu(qr))
+    want, _ = ops.memory_read(mk, mv, qk, qv, cu(mr), cu(qr), flags=ops.MR_EXACT_FP32)
     assert torch.allclose(got, want, atol=MR_ATOL, rtol=MR_RTOL)
+    via, _ = ops.memory_read(mk, mv, qk, qv, cu(mr), cu(qr))     # drop-in entry = staging + the same bank read
+    assert torch.allclose(via, want, atol=MR_ATOL, rtol=MR_RTOL)
     full = ops.MemoryBank(no, T, h, w, dev())
     for t in range(T):
         full.append(t, mk[:, :, t].contiguous(), torch.ones_like(mv[:, :, t]).contiguous())
@@ -756,3 +767,225 @@ def test_tiny_flownet_fused_bias_leaky(golden_dir):
     with torch.no_grad():
         a, f = tfn(frames), fused(frames)
     assert float((a - f).abs().max()) <= 1e-4 * max(1.0, float(a.abs().max()))
+
+
+# ----------------------------------------------------------------------------- round 2: pins and ranges
+def test_region_map_boxes_match_the_reference_box_finder(golden_dir, oracle_mod):
+    """G1 pinned by the REFERENCE: utils/helpers.py:93-102 get_bounding_boxes on 24 seeded soft masks
+    (K = 11, empty channels, values at exactly 0.5; tests/golden/cases.py).  With n_pts_threshold = 1 and
+    n_bbox_loose_pixels = 0 the CUDA kernel reduces to that function (reg_att_map_generator.cu:63-74)."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import cases
+    from rmnet_amd import ops
+    g = np.load(os.path.join(golden_dir, 'region_boxes.npz'))
+    assert len(cases.REGION_BOX_SHAPES) >= 20
+    for i, (B, K, H, W) in enumerate(cases.REGION_BOX_SHAPES):
+        m = cases.region_box_case(i)
+        assert float(m.astype(np.float64).sum()) == float(g['case%02d.checksum' % i])
+        want = cases.boxes_from_reference_tight(g['case%02d.tight' % i], K, H, W).reshape(B, K, 4)
+        att, bb, _ = ops.region_map(cu(m), 0.5, 1, 0)
+        assert np.array_equal(bb.cpu().numpy(), want), i
+        o_att, o_bb = oracle_mod.region_map(m, 0.5, 1, 0)
+        assert np.array_equal(o_bb, want) and np.array_equal(att.cpu().numpy(), o_att), i
+
+
+def test_bank_reads_the_reference_golden_vectors(golden_dir):
+    """The reference-generated MemoryReader vectors straight through the split-fp16 MemoryBank (the
+    dominant kernel bk_main), incl. `peaky` (logit scale 3: the running reference is bumped).  `tiny_p`
+    (De = 16 / Do = 32) is not a bank shape."""
+    from rmnet_amd import ops
+    g = np.load(os.path.join(golden_dir, 'memory_reader.npz'))
+    for name in ['dense', 'regional', 'allmasked_query', 'peaky']:
+        mk, mv = g[name + '.m_key'], g[name + '.m_val']
+        mr = g[name + '.mem_rects'] if name + '.mem_rects' in g.files else None
+        qr = g[name + '.qry_rects'] if name + '.qry_rects' in g.files else None
+        bank = _fill_bank(ops, mk, mv, mr, capacity=mk.shape[2] + 1)
+        got = bank.read(mk.shape[2], cu(g[name + '.q_key']), cu(g[name + '.q_val']), None if qr is None else cu(qr))
+        np.testing.assert_allclose(got.cpu().numpy(), g[name + '.mem_val'], atol=MR_ATOL, rtol=MR_RTOL, err_msg=name)
+        assert bank.overflow_count() == 0
+
+
+@pytest.mark.parametrize('kq_scale,v_scale', [(1e-3, 1e-3), (1e-2, 1e-2), (1.0, 1.0), (1.0, 1e2), (3.0, 1e2)])
+def test_bank_is_fp32_class_across_input_scales(kq_scale, v_scale, oracle_mod):
+    """Split-fp16 range claim.  Keys / queries times kq_scale, values times v_scale: 1e-3 is where the lo
+    plane would be subnormal without the 2^6 storage scale (absolute error floor 3e-8 -> 4.7e-10), 1e2
+    puts values up to ~500 (window: 1023.5), kq 3 gives logits of +-30.  (Larger key scales are not a
+    precision test any more: at |S| ~ 1e4 the fp32 reference itself resolves S to ~1e-2 only.)
+    Tolerance relative to the value scale, same constants as everywhere else."""
+    from rmnet_amd import ops
+    rng = np.random.RandomState(31)
+    mk, mv, qk, qv, mr, qr = _random_case(rng, 2, 3, 9, 13, regional=True)
+    mk, qk = (mk * kq_scale).astype(np.float32), (qk * kq_scale).astype(np.float32)
+    mv, qv = (mv * v_scale).astype(np.float32), (qv * v_scale).astype(np.float32)
+    want, _ = oracle_mod.regional_memory_read(mk, mv, qk, qv, mr, qr)
+    bank = _fill_bank(ops, mk, mv, mr)
+    got = bank.read(3, cu(qk), cu(qv), cu(qr)).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=MR_ATOL * v_scale, rtol=MR_RTOL)
+    assert bank.overflow_count() == 0
+    via, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), cu(mr), cu(qr))
+    np.testing.assert_allclose(via.cpu().numpy(), want, atol=MR_ATOL * v_scale, rtol=MR_RTOL)
+    if v_scale < 1:      # the small-value regime, measured against the value scale: fp32-class means ~1e-7
+        assert float(np.abs(got - want).max()) < 2e-6 * v_scale
+
+
+def test_out_of_window_values_are_detected_not_silently_clamped(oracle_mod):
+    """One value of 7e4 (beyond fp16) and one NaN-free 2e3 key: the bank COUNTS them
+    (rmnet_bank_overflow_offset), the drop-in entry falls back to the exact-fp32 kernel on the device and
+    still matches the oracle, and the tensor-backed bank (what the frame loop switches to) is exact too."""
+    from rmnet_amd import ops
+    rng = np.random.RandomState(32)
+    mk, mv, qk, qv, mr, qr = _random_case(rng, 2, 3, 9, 13, regional=True)
+    mr[:] = (0, 12, 0, 8)
+    qr[:] = (1, 11, 0, 8)
+    mv[1, 7, 2, 4, 5] = 7e4
+    mv[0, 100, 0, 0, 0] = -2e3
+    want, _ = oracle_mod.regional_memory_read(mk, mv, qk, qv, mr, qr)
+    bank = _fill_bank(ops, mk, mv, mr)
+    assert bank.overflow_count() == 2
+    via, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), cu(mr), cu(qr))          # device-side fallback
+    np.testing.assert_allclose(via.cpu().numpy(), want, atol=MR_ATOL, rtol=5e-5)
+    tb = ops.TensorBank(2, 4, 9, 13, dev())
+    for t in range(3):
+        tb.append(t, cu(mk[:, :, t]), cu(mv[:, :, t]), cu(mr[:, t]))
+    np.testing.assert_allclose(tb.read(3, cu(qk), cu(qv), cu(qr)).cpu().numpy(), want, atol=MR_ATOL, rtol=5e-5)
+    # and a clean input right after, through the same workspace-free entry: the fast path again
+    mv[1, 7, 2, 4, 5] = 0.5
+    mv[0, 100, 0, 0, 0] = 0.25
+    want2, _ = oracle_mod.regional_memory_read(mk, mv, qk, qv, mr, qr)
+    via2, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), cu(mr), cu(qr))
+    np.testing.assert_allclose(via2.cpu().numpy(), want2, atol=MR_ATOL, rtol=MR_RTOL)
+
+
+def test_frame_loop_redoes_a_clip_exactly_when_the_bank_overflows(oracle_mod):
+    """RMNet.forward checks the bank's overflow word once per clip and re-runs the clip on fp32 tensors +
+    the exact kernel; forced here by scaling the value head so that V leaves the fp16 window."""
+    from rmnet_amd.synthetic import synthetic_clip
+    prod, ref = _nets(oracle_mod)
+    frames, masks, flows, n_objects = synthetic_clip(3, 2, 96, 160, seed=4, size=1.4)
+    with torch.no_grad():
+        _, v4, _, _ = prod._encode_memory(frames[:, 0].to(dev()), masks[:, 0].to(dev()).float(), [1])
+        gain = 3000.0 / float(v4.abs().max())            # largest memorised value ~3000 > 1023.5
+        for net in (prod, ref):
+            net.kv_memory.value_conv.weight.mul_(gain)
+            net.kv_memory.value_conv.bias.mul_(gain)
+    calls = []
+    orig = prod.new_bank
+    prod.new_bank = lambda ctx, cap, exact=False: (calls.append(exact), orig(ctx, cap, exact))[1]
+    with torch.no_grad():
+        est = prod(frames, masks, flows, n_objects, 1).cpu()
+        est_cpu = ref(frames, masks, flows, n_objects, 1)
+    assert calls == [False, True]
+    assert float((est - est_cpu).abs().max()) < 5e-3          # (the decoder sees inputs `gain` times larger)
+    assert (est.argmax(2) == est_cpu.argmax(2)).float().mean() > 0.995
+
+
+@pytest.mark.parametrize('H,W,K', [(480, 854, 2), (720, 1280, 3)])
+def test_whole_loop_at_baseline_resolutions(H, W, K, oracle_mod):
+    """BASELINE configs[1] / configs[4] frame sizes: two frames of the device-resident loop (fused and
+    un-fused) against the CPU path -- the 30x54 / 45x80 grids, the 5-pixel pad of 854 and the fused warp
+    at full resolution."""
+    from rmnet_amd.synthetic import synthetic_clip
+    prod, ref = _nets(oracle_mod)
+    frames, masks, flows, n_objects = synthetic_clip(3, K, H, W, seed=H, size=1.6)
+    with torch.no_grad():
+        est_cpu = ref(frames, masks, flows, n_objects, 1)
+        est = prod(frames, masks, flows, n_objects, 1).cpu()
+        prod.fuse_epilogues()
+        est_f = prod(frames, masks, flows, n_objects, 1).cpu()
+    for e in (est, est_f):
+        assert float((e - est_cpu).abs().max()) < 1e-3
+        lab, lab_cpu = e.argmax(2).numpy(), est_cpu.argmax(2).numpy()
+        for k in range(1, K):
+            assert oracle_mod.iou(lab[:, 1:] == k, lab_cpu[:, 1:] == k) >= 0.999
+
+
+def test_multi_scale_inference_matches_the_reference(golden_dir):
+    """H1: rmnet_amd.helpers.multi_scale_inference (utils/helpers.py:44-78) against outputs of the
+    reference's own function on the same clip and weights (FRAME_SCALES [1.0] and [0.75, 1.0] + FLIP_LR),
+    host tensors in as from the reference's loader; var_or_cuda (utils/helpers.py:16-24)."""
+    import sys
+    from types import SimpleNamespace
+    sys.path.insert(0, golden_dir)
+    import cases
+    from rmnet_amd import helpers, networks
+    from rmnet_amd.rmnet import RMNet
+    from rmnet_amd.synthetic import synthetic_clip
+    from rmnet_amd.tiny_flownet import TinyFlowNet
+    g = np.load(os.path.join(golden_dir, 'multi_scale_inference.npz'))
+    net = networks.procedural_init_(RMNet(None)).to(dev()).eval()
+    tfn = networks.procedural_init_(TinyFlowNet(None)).to(dev()).eval()
+    c = cases.MSI_CLIP
+    frames, masks, _, n_objects = synthetic_clip(c['N'], c['K'], c['H'], c['W'], seed=c['seed'], size=c['size'])
+    for name, scales, flip in cases.MSI_CASES:
+        cfg = SimpleNamespace(TEST=SimpleNamespace(FRAME_SCALES=scales, FLIP_LR=flip, MEMORIZE_EVERY=c['memorize_every']))
+        with torch.no_grad():
+            flows, probs = helpers.multi_scale_inference(cfg, tfn, net, frames, masks, n_objects)
+        assert flows.shape == (1, c['N'], 2, c['H'], c['W']) and probs.shape == (1, c['N'], c['K'], c['H'], c['W'])
+        np.testing.assert_allclose(probs.cpu().numpy(), g[name + '.probs'].astype(np.float32), atol=3e-3, err_msg=name)
+        np.testing.assert_allclose(flows.cpu().numpy(), g[name + '.flows'].astype(np.float32), atol=5e-3, rtol=2e-3, err_msg=name)
+        assert (probs.argmax(2).cpu().numpy() == g[name + '.argmax']).mean() > 0.999
+    x = torch.arange(24.).view(2, 3, 4).transpose(1, 2)
+    y = helpers.var_or_cuda(x)
+    assert y.is_cuda and y.is_contiguous() and torch.equal(y.cpu(), x)
+    z = helpers.var_or_cuda(x, torch.device('cpu'))
+    assert not z.is_cuda and z.is_contiguous() and bool(g['var_or_cuda.contiguous'].all())
+    assert helpers.var_or_cuda(x, torch.device('cuda', 0)).device == torch.device('cuda', 0)
+
+
+def test_device_side_jaccard_on_the_gpu(oracle_mod):
+    """rmnet_amd.metrics on CUDA tensors (what evaluate_videos runs) vs the oracle's scalar IoU."""
+    from rmnet_amd import metrics
+    rng = np.random.RandomState(6)
+    N, H, W, n = 5, 33, 47, 3
+    pred, gt = rng.randint(0, n + 1, size=(N, H, W)), rng.randint(0, n + 1, size=(N, H, W))
+    pred[3][pred[3] == 1] = 0
+    gt[3][gt[3] == 1] = 0
+    j = metrics.jaccard_per_object(cu(pred), cu(gt), n)
+    assert j.is_cuda
+    j = j.cpu().numpy()
+    for t in range(N):
+        for o in range(1, n + 1):
+            assert abs(j[t, o - 1] - oracle_mod.iou(pred[t] == o, gt[t] == o)) < 1e-6
+    assert j[3, 0] == 1.0
+    assert abs(float(metrics.mean_jaccard(cu(pred), cu(gt), n)) - j[1:-1].mean()) < 1e-6
+
+
+def test_inference_only_guard_and_fuse_order(oracle_mod):
+    from rmnet_amd.synthetic import synthetic_clip
+    prod, _ = _nets(oracle_mod)
+    frames, masks, flows, n_objects = synthetic_clip(2, 2, 64, 96, seed=1)
+    prod.train()
+    with pytest.raises(RuntimeError, match='inference-only'):
+        prod(frames, masks, flows, n_objects, 1)
+    prod.eval()
+    est = prod(frames, masks, flows, n_objects, 1)          # grad mode on: runs under no_grad inside
+    assert not est.requires_grad
+    prod.fuse_epilogues()
+    sd = {k: v.clone() for k, v in prod.state_dict().items()}
+    for k in sd:
+        if k.endswith('running_var'):
+            sd[k] = sd[k] * 1.5
+    before = prod.encoder_query.res2[0]._s1.clone()
+    prod.load_state_dict(sd)                                 # the fused scale/shift snapshots are refreshed
+    assert not torch.equal(before, prod.encoder_query.res2[0]._s1)
+    prod.fuse_epilogues(False)
+    prod.fuse_for_inference()
+    with pytest.raises(RuntimeError, match='already folded'):
+        prod.fuse_epilogues()
+
+
+def test_bench_two_ranks_over_rccl():
+    """bench.py --gpus 2 with the nccl (= RCCL) backend; needs two GPUs on the box."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs >= 2 GPUs (the test box has %d); the N > 1 path is covered by the gloo tests' % torch.cuda.device_count())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                          '--master-addr', '127.0.0.1', '--master-port', '29517', os.path.join(root, 'bench.py'),
+                          '--gpus', '2', '--steps', '2', '--warmup', '1', '--clips-per-gpu', '1', '--no-cpu-baseline'],
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['value'] > 0

@@ -173,3 +173,85 @@ def test_sharded_video_inference_two_ranks_gloo():
         j = metrics.jaccard_per_object(pred.long(), labels.long(), no)[1:-1]
         want_j_num += float(j.sum()); want_j_den += j.numel()
     assert abs(j0 - want_j_num / want_j_den) < 1e-12 and abs(j1 - j0) < 1e-12
+
+
+def test_trunk_is_torchvision_resnet50(golden_dir):
+    """The ResNet-50 stand-in shared by the product, the oracle and the golden generator against an
+    EXTERNAL statement of torchvision's architecture (tests/golden/make_resnet50_kat.py): state-dict keys and
+    shapes of conv1..layer3, per-stage parameter counts (9,536 / 215,808 / 1,219,584 / 7,098,368), where
+    the stride sits, and the feature strides RMNet relies on (models/rmnet.py:57-64, 86-94)."""
+    import json
+    from rmnet_amd import networks
+    kat = json.load(open(os.path.join(golden_dir, 'resnet50_trunk_kat.json')))
+    trunk = networks.resnet50(pretrained=True)
+    sd = trunk.state_dict()
+    assert sorted(sd.keys()) == sorted(kat['state_dict'].keys())
+    for k, shp in kat['state_dict'].items():
+        assert list(sd[k].shape) == shp, k
+    mods = dict(trunk.named_modules())
+    for k, (stride, pad) in kat['conv_stride_padding'].items():
+        c = mods[k]
+        assert isinstance(c, torch.nn.Conv2d) and c.stride == (stride, stride) and c.padding == (pad, pad), k
+        assert c.bias is None and c.dilation == (1, 1) and c.groups == 1
+    count = lambda pre: sum(p.numel() for n, p in trunk.named_parameters() if n.split('.')[0] in pre)
+    assert count(('conv1', 'bn1')) == kat['trainable_parameters']['stem']
+    for st in ('layer1', 'layer2', 'layer3'):
+        assert count((st,)) == kat['trainable_parameters'][st]
+    mp = trunk.maxpool
+    assert (mp.kernel_size, mp.stride, mp.padding) == (kat['maxpool']['kernel'], kat['maxpool']['stride'], kat['maxpool']['padding'])
+    # feature strides / channels on a real input, through the encoder that uses the trunk
+    from rmnet_amd.rmnet import RMNet
+    net = RMNet(None).eval()
+    with torch.no_grad():
+        r4, r3, r2, c1, _ = net.encoder_query(torch.zeros(1, 3, 64, 96))
+    for t, name in ((c1, 'stem'), (r2, 'layer1'), (r3, 'layer2'), (r4, 'layer3')):
+        assert t.shape[2] == 64 // kat['output_stride'][name] and t.shape[3] == 96 // kat['output_stride'][name]
+    assert (r2.shape[1], r3.shape[1], r4.shape[1]) == tuple(kat['output_channels'][k] for k in ('layer1', 'layer2', 'layer3'))
+    # both encoders of RMNet carry exactly these tensors under the reference's names
+    rs = net.state_dict()
+    for k, shp in kat['state_dict'].items():
+        ref_k = k.replace('layer1', 'res2').replace('layer2', 'res3').replace('layer3', 'res4')
+        for enc in ('encoder_query', 'encoder_memory'):
+            assert list(rs[enc + '.' + ref_k].shape) == shp
+
+
+def test_compat_registers_the_reference_module_names():
+    """``import rmnet_amd.compat`` puts the two compiled-module names the
+    reference imports into sys.modules, with the reference's call signatures
+    (reg_att_map_generator_cuda.cpp:26-38: forward(mask, float, int, int) -> [att, bboxes];
+    flow_affine_transformation.cpp:87-90: update_optical_flow(flow, m1, m2))."""
+    import inspect
+    import sys
+    for name in ('reg_att_map_generator', 'flow_affine_transformation'):
+        sys.modules.pop(name, None)
+    from rmnet_amd import compat
+    compat.install()
+    ram, fat = sys.modules['reg_att_map_generator'], sys.modules['flow_affine_transformation']
+    assert list(inspect.signature(ram.forward).parameters) == ['mask', 'prob_threshold', 'n_pts_threshold', 'n_bbox_loose_pixels']
+    assert list(inspect.signature(fat.update_optical_flow).parameters)[:3] == ['optical_flow', 'tr_matrix1', 'tr_matrix2']
+    gen = ram.RegionalAttentionMapGenerator()
+    sig = inspect.signature(gen.forward)
+    assert [(p.name, p.default) for p in sig.parameters.values()][1:] == [('prob_threshold', 0.5), ('n_pts_threshold', 10), ('n_bbox_loose_pixels', 64)]
+    sentinel = object()
+    sys.modules['reg_att_map_generator'] = sentinel
+    compat.install()                                   # does not clobber a module somebody else registered ...
+    assert sys.modules['reg_att_map_generator'] is sentinel
+    compat.install(force=True)                         # ... unless asked to
+    assert sys.modules['reg_att_map_generator'] is ram
+    with pytest.raises(RuntimeError, match='CUDA'):    # CHECK_CUDA of the pybind layer (.cpp:14)
+        ram.forward(torch.zeros(1, 2, 8, 8), 0.5, 10, 64)
+    # the reference's own wrapper package binds to it unchanged (build container only)
+    ref = '/root/reference'
+    if os.path.isdir(ref):
+        import importlib
+        sys.path.insert(0, ref)
+        try:
+            for k in [k for k in sys.modules if k == 'extensions' or k.startswith('extensions.')]:
+                del sys.modules[k]
+            pkg = importlib.import_module('extensions.reg_att_map_generator')
+            assert pkg.reg_att_map_generator is ram
+            assert hasattr(pkg, 'RegionalAttentionMapGenerator')
+        finally:
+            sys.path.remove(ref)
+            for k in [k for k in sys.modules if k == 'extensions' or k.startswith('extensions.') or k == 'utils' or k.startswith('utils.')]:
+                del sys.modules[k]

@@ -177,3 +177,26 @@ def test_tiny_flownet_matches_reference(golden_dir):
     with torch.no_grad():
         fl = net(torch.from_numpy(g['frames']))
     np.testing.assert_allclose(fl.numpy(), g['flows'], atol=1e-4, rtol=1e-4)
+
+
+def test_region_map_boxes_match_the_reference_box_finder(oracle_mod, golden_dir):
+    """The oracle's region map against the REFERENCE's own box finder (utils/helpers.py:93-102
+    get_bounding_boxes, run by tests/golden/make_golden.py on the seeded masks of tests/golden/cases.py):
+    with (thr, n_pts_threshold = 1, n_bbox_loose_pixels = 0) reg_att_map_generator.cu:30-77 is exactly that
+    function plus the empty-channel fallback and the untouched channel 0."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import cases
+    g = np.load(os.path.join(golden_dir, 'region_boxes.npz'))
+    n_empty = n_k11 = 0
+    for i, (B, K, H, W) in enumerate(cases.REGION_BOX_SHAPES):
+        m = cases.region_box_case(i)
+        assert float(m.astype(np.float64).sum()) == float(g['case%02d.checksum' % i])   # same inputs as the reference saw
+        tight = g['case%02d.tight' % i]
+        n_empty += int((tight[:, 0] < 0).sum())
+        n_k11 += K == 11
+        want = cases.boxes_from_reference_tight(tight, K, H, W).reshape(B, K, 4)
+        att, bb = oracle_mod.region_map(m, 0.5, 1, 0)
+        assert np.array_equal(bb, want), i
+        assert np.array_equal(att, box_map(want, H, W)), i
+    assert len(cases.REGION_BOX_SHAPES) >= 20 and n_empty >= 5 and n_k11 >= 4
