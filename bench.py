@@ -17,13 +17,22 @@ weak scaling, no data-path collective) and ``value`` = N * clips * K / max-over-
 The JSON line also carries
   roofline     -- the dominant hand-written kernel (bk_main, the regional memory read) timed live
                   with HIP events recorded on its own stream around every launch of the timed
-                  region: achieved = algorithmic bytes per launch / mean duration, vs 8 TB/s HBM;
+                  region.  The kernel is bound by the matrix pipe under the chip's power cap (DESIGN.md
+                  section 5), so bound = "mfma": achieved = executed split-fp16 MFMA flops / mean
+                  duration vs the 2.5 PFLOP/s dense f16 peak.  BASELINE.json's headline figure --
+                  algorithmic bytes per launch / duration vs 8 TB/s HBM -- is kept beside it as
+                  roofline.hbm (frac = the kernel alone, op_frac = kernel + combine);
+  extras       -- single-stream and free-running (memorize_every = 5, N = 67, fed-back masks) fps, and
+                  kernel figures for BASELINE configs[2] / configs[4] and the other hand-written kernels,
+                  each against SURVEY.md section 8d's byte formulas (rank 0, N = 1 only);
   cpu_baseline -- the oracle's CPU restatement of the same path timed on this box's host cores
-                  (rank 0, N = 1 only; bounded sample).
+                  (rank 0, N = 1 only; bounded sample), plus the three native ops alone at all cores
+                  and at 8 threads.
 """
 
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -81,28 +90,176 @@ class HipEvents:
         return float(ms.value)
 
 
-def cpu_baseline(n_frames=5):
-    """Oracle CPU path (plain torch + C ops) on a bounded sample: one 480x854 clip, 1 object,
-    memorize_every = 1 so the memory grows 1..n_frames (mean T = 3 for 5 frames -- slightly cheaper
-    than the pinned T = 5, i.e. generous to the CPU)."""
+def _median_time(fn, reps):
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def cpu_baseline(n_frames=3):
+    """Oracle CPU path (plain torch + C ops, oracle/) on a bounded sample of the bench workload: one
+    480x854 clip, 1 object, memory PINNED at T = 5 exactly as on the GPU (4 committed frames pre-filled
+    untimed; every timed frame = TinyFlowNet + memorize frame t-1 + cat -> T = 5 + warp/boxes + segment +
+    soft-max).  Plus the three native ops alone, at all cores and at 8 threads."""
+    import numpy as np
+    import torch.nn.functional as F
     from oracle import oracle
     from rmnet_amd import networks
     from rmnet_amd.synthetic import synthetic_clip
     from rmnet_amd.tiny_flownet import TinyFlowNet
     torch.set_grad_enabled(False)
+    all_threads = torch.get_num_threads()
     net = networks.procedural_init_(oracle.OracleRMNet(reader='torch')).eval()
     tfn = networks.procedural_init_(TinyFlowNet(None)).eval()
-    frames, masks, _, n_objects = synthetic_clip(n_frames + 1, K_CH, H, W, seed=0, size=2.1)
-    warm = frames[:, :2]
-    net(warm, masks[:, :2], tfn(warm), n_objects[:, :2], 1)            # warm-up (1 frame)
+    frames, masks, _, n_objects = synthetic_clip(T_MEM + n_frames, K_CH, H, W, seed=0, size=2.1)
+    masks = masks.float()
+    keys = values = None
+    for t in range(T_MEM - 1):                                  # untimed: the 4 committed frames
+        pk, pv, _ = net.memorize(frames[:, t], masks[:, t], [K_CH - 1])
+        keys = pk if keys is None else torch.cat([keys, pk], dim=3)
+        values = pv if values is None else torch.cat([values, pv], dim=3)
+
+    def one_frame(t):
+        flow = tfn._forward(frames[:, t], frames[:, t - 1])
+        pk, pv, _ = net.memorize(frames[:, t - 1], masks[:, t - 1], [K_CH - 1])
+        tk, tv = torch.cat([keys, pk], dim=3), torch.cat([values, pv], dim=3)      # T = 5
+        att, _ = net.get_att_map(masks[:, t - 1], flow)
+        return F.softmax(net.segment(frames[:, t], att, tk, tv, [K_CH - 1]), dim=1)
+
+    one_frame(T_MEM - 1)                                        # warm-up
     t0 = time.perf_counter()
-    flows = tfn(frames)
-    net(frames, masks, flows, n_objects, 1)
+    for i in range(n_frames):
+        one_frame(T_MEM + i)
     dt = time.perf_counter() - t0
-    return {'value': round(n_frames / dt, 4), 'unit': 'frames/s', 'cores': torch.get_num_threads(),
-            'kind': 'port',
-            'sample': '%d frames of one 480x854 clip, 1 object, memorize_every=1 (T=1..%d), TinyFlowNet '
-                      'included, fp32, torch %d threads; %.1f s' % (n_frames, n_frames, torch.get_num_threads(), dt)}
+
+    # ---- the native ops alone
+    g = torch.Generator().manual_seed(0)
+    h, w = 30, 54
+    mk = torch.randn(1, DE, T_MEM, h, w, generator=g) * 0.6
+    mv = torch.randn(1, DO, T_MEM, h, w, generator=g)
+    qk = torch.randn(1, DE, h, w, generator=g) * 0.6
+    qv = torch.randn(1, DO, h, w, generator=g)
+    soft = np.zeros((1, K_CH, 480, 864), np.float32)
+    soft[0, 1, 120:330, 250:600] = 0.9
+    rng = np.random.RandomState(0)
+    flow = ((rng.rand(H, W, 2) - 0.5) * 20).astype(np.float32)
+    m1 = (np.eye(2, 3) + (rng.rand(2, 3) - 0.5) * 0.1).astype(np.float32)
+    m2 = (np.eye(2, 3) + (rng.rand(2, 3) - 0.5) * 0.1).astype(np.float32)
+    ops = {}
+    for label, nt in (('all_cores', all_threads), ('8_threads', min(8, all_threads))):
+        torch.set_num_threads(nt)
+        oracle.set_num_threads(nt)
+        oracle.torch_memory_read(mk, mv, qk, qv)
+        ops[label] = {
+            'threads': nt,
+            'memory_read_T5_480p_s': round(_median_time(lambda: oracle.torch_memory_read(mk, mv, qk, qv), 3), 4),
+            'region_map_K2_480x864_s': round(_median_time(lambda: oracle.region_map(soft), 5), 5),
+        }
+    torch.set_num_threads(all_threads)
+    oracle.set_num_threads(all_threads)
+    ops['flow_affine_480x854_1thread_s'] = round(_median_time(lambda: oracle.flow_affine(flow, m1, m2), 5), 5)
+    ops['note'] = ('memory_read = models/rmnet.py:147-165 with torch CPU ops (the survey measured 0.28 s for the reference '
+                   'itself on 8 vCPUs); region_map / flow_affine = oracle/rmnet_oracle.c (the reference runs flow_affine '
+                   'single-threaded in DataLoader workers)')
+    return {'value': round(n_frames / dt, 4), 'unit': 'frames/s', 'cores': all_threads, 'kind': 'port',
+            'sample': '%d frames of one 480x854 clip, 1 object, memory pinned at T=%d (4 committed frames pre-filled '
+                      'untimed), TinyFlowNet included, fp32, torch %d threads; %.1f s'
+                      % (n_frames, T_MEM, all_threads, dt),
+            'ops': ops}
+
+
+def source_hash():
+    """sha256 over the read kernels' sources: stamps profiles/*_hbm_traffic.json so that a PMC figure taken
+    with an older kernel is never reported for a newer one."""
+    hsh = hashlib.sha256()
+    for fn in ('bank.hip', 'memory_read.hip', 'common.h'):
+        hsh.update(open(os.path.join(ROOT, 'rmnet_amd', 'csrc', fn), 'rb').read())
+    return hsh.hexdigest()[:16]
+
+
+def kernel_figures(dev, events):
+    """Hand-written kernels alone (HIP events on the launch stream, empty-bracket floor subtracted), each
+    with SURVEY.md section 8d's algorithmic bytes: BASELINE configs[2] (5 objects) and configs[4] (720p,
+    3 objects, T = 20) through the bank read, the region map, the flow update, the bank append."""
+    import numpy as np
+    from rmnet_amd import ops
+    hip, ev = events.hip, events.ev
+    st = torch.cuda.current_stream(dev).cuda_stream
+    floor = events.floor_us(st)
+
+    def bracket(fn, reps=12, warm=3):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            hip.hipEventRecord(ctypes.c_void_p(ev[0]), ctypes.c_void_p(st))
+            fn()
+            hip.hipEventRecord(ctypes.c_void_p(ev[1]), ctypes.c_void_p(st))
+            torch.cuda.synchronize()
+            ts.append(events.elapsed_ms(ev[0], ev[1]) * 1e3 - floor)
+        return float(np.mean(ts))
+
+    def gbs(nbytes, us):
+        return {'us': round(us, 2), 'algorithmic_bytes': int(nbytes), 'GBps': round(nbytes / us / 1e3, 1),
+                'hbm_frac': round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)}
+
+    out = {}
+    g = torch.Generator().manual_seed(1)
+    rng = np.random.RandomState(2)
+    for name, (no, T, h, w, dense) in (('cfg3_5obj_T5_480p_boxes46', (5, 5, 30, 54, False)),
+                                       ('cfg5_3obj_T20_720p_boxes46', (3, 20, 45, 80, False)),
+                                       ('cfg5_3obj_T20_720p_dense', (3, 20, 45, 80, True))):
+        k = (torch.randn(no, DE, h, w, generator=g) * 0.6).to(dev)
+        v = torch.randn(no, DO, h, w, generator=g).to(dev)
+        rects = []
+        for _ in range(no):
+            rh, rw = int(h * 0.68), int(w * 0.68)
+            y0, x0 = rng.randint(0, h - rh + 1), rng.randint(0, w - rw + 1)
+            rects.append((0, w - 1, 0, h - 1) if dense else (x0, x0 + rw - 1, y0, y0 + rh - 1))
+        r = torch.tensor(rects, dtype=torch.int32, device=dev)
+        bank = ops.MemoryBank(no, T, h, w, dev)
+        for t in range(T):
+            bank.append(t, k, v, r)
+        e3 = (ev[2], ev[3], ev[4])
+        for _ in range(3):
+            bank.read(T, k, v, r)
+        torch.cuda.synchronize()
+        mm, cc = [], []
+        for _ in range(8):
+            bank.read(T, k, v, r, events=e3)
+            torch.cuda.synchronize()
+            mm.append(events.elapsed_ms(e3[0], e3[1]) * 1e3 - floor)
+            cc.append(events.elapsed_ms(e3[1], e3[2]) * 1e3 - floor)
+        ab = algorithmic_bytes(no, T, h, w)
+        fig = gbs(ab, float(np.mean(mm)))
+        fig['combine_us'] = round(float(np.mean(cc)), 2)
+        fig['op_hbm_frac'] = round(ab / (np.mean(mm) + np.mean(cc)) / 1e3 / HBM_PEAK_GBS, 4)
+        out[name] = fig
+        if name.startswith('cfg3'):
+            out['bk_append_5obj_480p'] = gbs(2 * 4 * (DE + DO) * h * w * no, bracket(lambda: bank.append(T - 1, k, v, r)))
+        del bank
+    # region map: 2 * 4 * B * K * H * W + 16 * B * K bytes (mask read once, map written once)
+    for K_ in (2, 11):
+        m = torch.zeros(1, K_, 480, 864, device=dev)
+        m[0, 1:, 120:330, 250:600] = 0.9
+        out['region_map_K%d_480x864' % K_] = gbs(2 * 4 * K_ * 480 * 864 + 16 * K_, bracket(lambda: ops.region_map(m)))
+        out['region_boxes_only_K%d_480x864' % K_] = gbs(4 * K_ * 480 * 864 + 16 * K_,
+                                                        bracket(lambda: ops.region_map(m, want_map=False, cell_grid=(0, 0, 16, 30, 54))))
+    m = torch.zeros(8, 2, 480, 854, device=dev)
+    m[:, 1, 120:330, 250:600] = 0.9
+    fl = torch.full((8, 2, 480, 854), -2.5, device=dev)
+    out['region_boxes_warped_8x2_480x854'] = gbs(4 * 8 * (2 + 2) * 480 * 854 + 16 * 16,
+                                                 bracket(lambda: ops.region_map(m, want_map=False, flow=fl, cell_grid=(5, 0, 16, 30, 54))))
+    f = ((torch.rand(480, 854, 2, generator=g) - 0.5) * 20).to(dev)
+    m1 = torch.tensor([[1.02, 0.01, 1.5], [-0.01, 0.98, -2.0]], device=dev)
+    out['flow_affine_480x854'] = gbs(16 * 480 * 854 + 48, bracket(lambda: ops.flow_affine(f, m1, m1)))
+    out['event_floor_us'] = round(floor, 2)
+    return out
 
 
 def main():
@@ -111,6 +268,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the single-stream / free-running / per-kernel figures')
     ap.add_argument('--no-miopen-find', action='store_true',
                     help='leave torch.backends.cudnn.benchmark off (MIOpen immediate mode; ~5 %% slower convs)')
     ap.add_argument('--no-fuse-epilogue', action='store_true',
@@ -168,7 +326,7 @@ def main():
         net.frame_step(ctx, bank, frames[:, t - 1], masks[:, t - 1], frames[:, t], flow, commit=True)
     assert bank.committed == T_MEM - 1
 
-    events = HipEvents(3 * args.steps)
+    events = HipEvents(max(3 * args.steps, 8))
     ev_floor_us = events.floor_us(torch.cuda.current_stream(dev).cuda_stream)
 
     def frame_body(prev_frame, prev_mask, cur_frame):
@@ -251,12 +409,59 @@ def main():
     nqt = (mq + 1 + 63) // 64
     mfma_flops = float((nqt * 64 * njt * 32).sum()) * (DE + DO) * 2 * 3
     mfma_tflops = mfma_flops / (main_avg * 1e-3) / 1e12
-    traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'mr_main_hbm_traffic.json')   # from a separate --pmc pass
+    comb_avg = max(sum(comb_ms) / len(comb_ms) - ev_floor_us * 1e-3, 1e-6)
+    op_achieved = abytes / ((main_avg + comb_avg) * 1e-3) / 1e9
+    traffic, traffic_note = None, 'no PMC file for this kernel version'
+    tpath = os.path.join(ROOT, 'profiles', 'bk_main_hbm_traffic.json')   # from separate --pmc passes (tools/pmc_traffic.sh)
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
-        if int(tj.get('algorithmic_bytes_per_launch', -1)) == int(abytes):   # measured for this very workload
-            traffic = tj.get('hbm_bytes_per_launch')
+        if tj.get('source_hash') == source_hash() and int(tj.get('algorithmic_bytes_per_launch', -1)) == int(abytes):
+            traffic, traffic_note = tj.get('hbm_bytes_per_launch'), 'profiles/bk_main_hbm_traffic.json (same kernel sources, same workload)'
+        else:
+            traffic_note = 'profiles/bk_main_hbm_traffic.json is from other kernel sources or another workload: not reported'
+
+    extras = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = {}
+        # ---- one clip alone (single stream): same step, B = 1
+        ctx1 = net._ClipContext(net, 1, K_CH, H, W, [K_CH - 1], dev)
+        bank1 = net.new_bank(ctx1, T_MEM)
+        f1, m1 = frames[:1], masks[:1]
+        for t in range(1, T_MEM):
+            net.frame_step(ctx1, bank1, f1[:, t - 1], m1[:, t - 1], f1[:, t], tfn._forward(f1[:, t], f1[:, t - 1]), commit=True)
+        net._profile_events = None
+
+        def step1(i):
+            t = T_MEM + (i % (n_clip - T_MEM))
+            out1 = net.frame_step(ctx1, bank1, f1[:, t - 1], m1[:, t - 1], f1[:, t], tfn._forward(f1[:, t], f1[:, t - 1]), commit=False)
+            return out1[1] if isinstance(out1, tuple) else torch.softmax(out1, dim=1)
+        for i in range(5):
+            step1(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(20):
+            step1(i)
+        torch.cuda.synchronize()
+        extras['single_stream_fps'] = round(20 / (time.perf_counter() - t1), 2)
+        # ---- free-running loop: RMNet.forward on one 67-frame clip (DAVIS-val mean length), memorize_every = 5,
+        #      estimated masks fed back (the real feedback edge), TinyFlowNet inside the timed region
+        from rmnet_amd.synthetic import synthetic_clip as _clip
+        N_FREE = 67
+        ff, fm, _, fn_obj = _clip(N_FREE, K_CH, H, W, seed=7, size=2.1)
+        ff = ff.to(dev)
+        net(ff[:, :6], fm[:, :6], tfn(ff[:, :6]), fn_obj[:, :6], 5)          # warm-up
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        est = net(ff, fm, tfn(ff), fn_obj, 5)
+        torch.cuda.synchronize()
+        dt_free = time.perf_counter() - t1
+        cover = float((est[0, 1:, 1] > 0.5).float().mean())
+        extras['free_running'] = {'fps': round((N_FREE - 1) / dt_free, 2), 'frames': N_FREE, 'memorize_every': 5,
+                                  'memory_frames_at_end': 14, 'clips': 1,
+                                  'note': 'RMNet.forward + TinyFlowNet on one clip, masks fed back; with random-init weights the '
+                                          'estimated object covers %.0f %% of the frame on average (boxes follow it)' % (100 * cover)}
+        del ff, est
+        extras['kernels'] = kernel_figures(dev, events)
 
     if rank == 0:
         line = {
@@ -271,26 +476,38 @@ def main():
                                    'at T=5, TinyFlowNet + memorize + regional read + decoder per frame; '
                                    'clips_per_gpu independent clips batched per GPU',
                        'weights': 'procedural random-init (no checkpoint offline)',
-                       'prev_mask': 'synthetic blob mask of frame t-1 (object ~18 % of the frame, boxes ~46 % of the cells)',
+                       'prev_mask': 'synthetic blob mask of frame t-1 (object ~18 % of the frame, boxes ~46 % of the cells); '
+                                    'extras.free_running feeds the estimated masks back instead',
                        'sharding': 'one clip per rank',
                        'miopen_find': not args.no_miopen_find, 'channels_last': bool(args.channels_last),
                        'hip_graph': bool(args.graph), 'clips_per_gpu': B,
                        'batchnorm_folded': bool(args.fold_bn),
                        'fused_epilogues': bool(not args.fold_bn and not args.no_fuse_epilogue and not args.channels_last)},
-            'roofline': {'bound': 'hbm', 'kernel': 'bk_main (fused regional memory read, split-fp16 MFMA bank kernel)',
-                         'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                         'algorithmic_bytes_per_launch': abytes, 'launches': args.steps,
+            'roofline': {'bound': 'mfma', 'kernel': 'bk_main (fused regional memory read, split-fp16 MFMA bank kernel)',
+                         'achieved': round(mfma_tflops, 1), 'peak': 2500.0, 'unit': 'TFLOP/s',
+                         'frac': round(mfma_tflops / 2500.0, 4), 'traffic': traffic, 'traffic_source': traffic_note,
+                         'why_mfma': 'three split-fp16 terms = 120 v_mfma_f32_16x16x32_f16 per SIMD per 64x32 tile; the chip is '
+                                     'power-capped under this load (shader clock 1.5-1.75 GHz inside the kernel, tools/bk_clk.py); a pure '
+                                     'random-data MFMA loop sustains 1.9 PFLOP/s (tools/ubench/mfma_power.hip); HBM traffic is ~0.25x the '
+                                     'algorithmic bytes',
+                         'flops_counted': 'executed: 3 split terms over the compacted 64-query x 32-cell tiles; the dense one-term algorithm '
+                                          '(SURVEY 8d: 2*THW*hw*(De+Do) per object-frame) would be %.1f TFLOP/s' %
+                                          (B * (K_CH - 1) * 2.0 * T_MEM * ctx.h * ctx.w * ctx.h * ctx.w * (DE + DO) / (main_avg * 1e-3) / 1e12),
+                         'hbm': {'note': "BASELINE.json's headline figure: SURVEY 8d algorithmic bytes per launch / duration vs 8 TB/s",
+                                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                 'frac': round(achieved / HBM_PEAK_GBS, 4),
+                                 'op_frac': round(op_achieved / HBM_PEAK_GBS, 4),
+                                 'algorithmic_bytes_per_launch': abytes},
+                         'launches': args.steps,
                          'avg_us': round(main_avg * 1e3, 2), 'avg_us_event_bracket': round(main_raw * 1e3, 2),
                          'event_floor_us': round(ev_floor_us, 2), 'min_us_event_bracket': round(min(main_ms) * 1e3, 2),
-                         'combine_avg_us_event_bracket': round(sum(comb_ms) / len(comb_ms) * 1e3, 2),
-                         'mfma': {'executed_tflops': round(mfma_tflops, 1), 'peak_f16_dense_tflops': 2500.0,
-                                  'frac': round(mfma_tflops / 2500.0, 4),
-                                  'note': 'v_mfma_f32_16x16x32_f16, three split-fp16 terms (hi*hi+hi*lo+lo*hi) over the '
-                                          'compacted 64-query x 32-cell tiles actually executed'},
-                         'timing': 'hipEventRecord on the launch stream around every bk_main of the timed region; '
+                         'combine_avg_us': round(comb_avg * 1e3, 2),
+                         'op_avg_us': round((main_avg + comb_avg) * 1e3, 2),
+                         'timing': 'hipEventRecord on the launch stream around every bk_main / mr_combine of the timed region; '
                                    'avg_us = bracket mean minus the empty-bracket floor measured the same way'},
         }
+        if extras is not None:
+            line['extras'] = extras
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)
