@@ -370,8 +370,13 @@ inline int comb_channels(int no) { return no <= 2 ? 16 : 32; }
 //        box only (mean-slot vector, q_val * 0).  Skipped when nothing is masked.
 // The bank kernel keeps its running reference in the log2 domain (2^x soft-max), mr_main in the
 // natural one; a.bank_area tells which.
+// blocks [copy_x0, gridDim.x) (only when copy_x0 > 0): the q_val half of the cat as a streaming copy --
+//        mem_val[o][Do + d][:] = q_val[o][d][:] * box, 16 bytes per lane along the channel rows (needs
+//        h * w % 4 == 0, as on RMNet's grids).  The query-tile blocks used to carry it in 256-byte runs
+//        per channel, which cost 14.5 of the kernel's 35 us at 8 objects; as blocks of their own the copy
+//        overlaps the latency chain of the merge blocks.
 template <bool REGIONAL, int kCombCh>
-__global__ __launch_bounds__(kThreads, kCombCh == 16 ? 6 : 5) void mr_combine(const KArgs a, int nqt_max) {   // (register cap: many resident workgroups hide the latency chain; LDS allows 5 at 32 channels)
+__global__ __launch_bounds__(kThreads, kCombCh == 16 ? 6 : 5) void mr_combine(const KArgs a, int nqt_max, int copy_x0) {   // (register cap: many resident workgroups hide the latency chain; LDS allows 5 at 32 channels)
   constexpr int kCombDt = kCombCh / 16;    // = channel tiles (fragments) per query tile and split
   __shared__ float Wt[kMaxSplits][kQT];
   __shared__ float Wm[kMaxSplits];
@@ -409,6 +414,26 @@ __global__ __launch_bounds__(kThreads, kCombCh == 16 ? 6 : 5) void mr_combine(co
     }
     return r;
   };
+  if (copy_x0 > 0 && (int)blockIdx.x >= copy_x0) {
+    const int hw4 = a.hw >> 2, n4 = kCombCh * hw4, d0c = blockIdx.y * kCombCh;
+    const Rect rc = REGIONAL ? pl.qr : Rect{0, a.w - 1, 0, a.h - 1};
+    const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(a.qv + ((size_t)o * kDo + d0c) * a.hw);
+    f32x4* __restrict__ dst = reinterpret_cast<f32x4*>(a.out + ((size_t)o * 2 * kDo + kDo + d0c) * a.hw);
+    const int stride = ((int)gridDim.x - copy_x0) * kThreads;
+    for (int i = ((int)blockIdx.x - copy_x0) * kThreads + tid; i < n4; i += stride) {
+      f32x4 v = src[i];                                   // (rows of a channel group are contiguous: index = d * hw4 + c4)
+      const int d = i / hw4, cell = (i - d * hw4) << 2;
+      int cy = cell / a.w, cx = cell - cy * a.w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = rc.contains(cy, cx) ? v[e] : v[e] * 0.0f;  // q_val * box (:358), x*0 semantics
+        if (++cx == a.w) { cx = 0; ++cy; }
+      }
+      dst[i] = v;
+    }
+    return;
+  }
+  const bool qv_here = copy_x0 == 0;                      // the merge / fill blocks below write the q_val half themselves
   const bool log2d = a.bank_area != nullptr && !(a.gate && __builtin_amdgcn_readfirstlane(*a.gate) != 0);
   const float vun = log2d ? kBankValueUnscale : 1.0f;   // the bank stores values times 2^6
   const int qi = tid & 63, sl = tid >> 6;
@@ -553,7 +578,7 @@ __global__ __launch_bounds__(kThreads, kCombCh == 16 ? 6 : 5) void mr_combine(co
     for (int dd = sl; dd < kCombCh; dd += 4) {
       const int d = d0 + dd;
       if (!(RMNET_COMB_ABL & 2)) out[(size_t)d * a.hw] = Tm[dd];
-      if (!(RMNET_COMB_ABL & 1)) out[(size_t)(kDo + d) * a.hw] = qv[(size_t)d * a.hw] * 0.0f;   // q_val * box (:358), x*0 semantics
+      if (!(RMNET_COMB_ABL & 1) && qv_here) out[(size_t)(kDo + d) * a.hw] = qv[(size_t)d * a.hw] * 0.0f;   // q_val * box (:358), x*0 semantics
     }
     return;
   }
@@ -609,7 +634,7 @@ __global__ __launch_bounds__(kThreads, kCombCh == 16 ? 6 : 5) void mr_combine(co
     for (int dd = sl; dd < kCombCh; dd += 4) {
       const int d = d0 + dd;
       outo[(size_t)d * a.hw + cell] = Tt[dd][qi];
-      outo[(size_t)(kDo + d) * a.hw + cell] = qvo[(size_t)d * a.hw + cell];     // cat(mem, q_val), :163
+      if (qv_here) outo[(size_t)(kDo + d) * a.hw + cell] = qvo[(size_t)d * a.hw + cell];     // cat(mem, q_val), :163
     }
     return;
   }
@@ -623,9 +648,11 @@ __global__ __launch_bounds__(kThreads, kCombCh == 16 ? 6 : 5) void mr_combine(co
 #pragma unroll 8
     for (int dd = sl; dd < kCombCh; dd += 4) {
       const int d = d0 + dd;
-      const float x = (RMNET_COMB_ABL & 1) ? 0.0f : qvo[(size_t)d * a.hw + cell];
       if (!(RMNET_COMB_ABL & 2)) outo[(size_t)d * a.hw + cell] = inside ? Tt[dd][q] : Tm[dd];
-      if (!(RMNET_COMB_ABL & 1)) outo[(size_t)(kDo + d) * a.hw + cell] = inside ? x : x * 0.0f;   // q_val * box (:358), x*0 semantics
+      if (!(RMNET_COMB_ABL & 1) && qv_here) {
+        const float x = qvo[(size_t)d * a.hw + cell];
+        outo[(size_t)(kDo + d) * a.hw + cell] = inside ? x : x * 0.0f;   // q_val * box (:358), x*0 semantics
+      }
     }
   }
 }
@@ -732,13 +759,23 @@ inline bool fast_shape(int De, int Do, int T, int flags) {
   return De == kDe && Do == kDo && T <= kMaxT && !(flags & RMNET_MR_FORCE_GENERIC);
 }
 
+#ifndef RMNET_COMB_COPY_BLOCKS
+#define RMNET_COMB_COPY_BLOCKS 8   // copy blocks per (object, channel group); measured at 8 objects: 1: 46 us, 4: 35, 8: 30-31, 16-32: 32 (39 without)
+#endif
 inline void launch_combine(bool regional, int cch, dim3 grid, hipStream_t st, const KArgs& a, int nqt_max) {
+  // the q_val half as copy blocks of their own when the rows can be moved 16 bytes at a time
+  int copy_x0 = 0;
+  if (a.hw % 4 == 0 && (reinterpret_cast<uintptr_t>(a.qv) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
+      !(RMNET_COMB_ABL & 1)) {
+    copy_x0 = (int)grid.x;
+    grid.x += RMNET_COMB_COPY_BLOCKS;
+  }
   if (regional) {
-    if (cch == 16) hipLaunchKernelGGL((mr_combine<true, 16>), grid, dim3(kThreads), 0, st, a, nqt_max);
-    else hipLaunchKernelGGL((mr_combine<true, 32>), grid, dim3(kThreads), 0, st, a, nqt_max);
+    if (cch == 16) hipLaunchKernelGGL((mr_combine<true, 16>), grid, dim3(kThreads), 0, st, a, nqt_max, copy_x0);
+    else hipLaunchKernelGGL((mr_combine<true, 32>), grid, dim3(kThreads), 0, st, a, nqt_max, copy_x0);
   } else {
-    if (cch == 16) hipLaunchKernelGGL((mr_combine<false, 16>), grid, dim3(kThreads), 0, st, a, nqt_max);
-    else hipLaunchKernelGGL((mr_combine<false, 32>), grid, dim3(kThreads), 0, st, a, nqt_max);
+    if (cch == 16) hipLaunchKernelGGL((mr_combine<false, 16>), grid, dim3(kThreads), 0, st, a, nqt_max, copy_x0);
+    else hipLaunchKernelGGL((mr_combine<false, 32>), grid, dim3(kThreads), 0, st, a, nqt_max, copy_x0);
   }
 }
 
