@@ -15,9 +15,11 @@
  *
  * Pinning (see oracle/README.md): flow_affine is checked bit-for-bit against the
  * reference C++ compiled from /root/reference (oracle/_ref); memory_read against
- * golden vectors captured from the reference's own MemoryReader; the region map has
- * no runnable reference here (CUDA only) and is pinned by hand-computed known-answer
- * tests -- "parity unpinned" for that one op, stated in DESIGN.md.
+ * golden vectors captured from the reference's own MemoryReader; the region map's
+ * box finder against the reference's own Python box finder
+ * (utils/helpers.py:93-102, tests/golden/region_boxes.npz) and its loosen / clamp /
+ * fallback branches by hand-computed known-answer tests (the .cu needs nvcc and a
+ * CUDA device: it cannot run here).
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
  */

@@ -4,9 +4,10 @@
 Clips are independent (frame t needs the mask of frame t-1, but clips share nothing --
 models/rmnet.py:410-450), so the path shards across videos: one process per GPU, video v goes to a
 rank chosen by a longest-first greedy balance of its cost N*n_objects, weights are replicated and
-there is NO communication while a clip runs.  The only collective is the gather of the per-video
-outputs (uint8 label maps) at the end: a flat gather to rank 0, which on MI355X uses each peer's
-direct xGMI link (the backend is "nccl" = RCCL on ROCm; "gloo" on CPU for the tests).
+there is NO communication while a clip runs.  The only collectives are a 32-byte-per-video header
+all_gather and ONE ``gather`` of the per-video outputs (uint8 label maps) to rank 0 at the end, which on
+MI355X uses each peer's direct xGMI link (the backend is "nccl" = RCCL on ROCm; "gloo" on CPU for the
+tests).
 
 The reference has no counterpart: its DataParallel wrapper runs batch size 1 on one GPU
 (core/inference.py:23-37) and utils/eval_server.py:78-87 shards checkpoints, not videos.
@@ -91,20 +92,24 @@ def gather_label_maps(results, n_videos, dst=0):
 
     ``results``: dict video_id -> uint8 tensor [N,H,W] (this rank's videos; on the rank's device for
     nccl, CPU for gloo).  Two phases: (1) all_gather of a fixed-size int64 header table
-    [n_videos, 4] = (owner_has_it, N, H, W); (2) one all_gather of the ranks' payloads padded to the
-    largest rank payload (flat uint8) -- RCCL has no variable-size gather, padding costs at most one
-    extra clip per rank over xGMI.  Returns {video_id: tensor} on ``dst`` and {} elsewhere."""
+    [n_videos, 4] = (owner_has_it, N, H, W) -- 32 bytes per video, every rank learns every size (one host
+    read of the whole table, not one per entry); (2) ONE ``gather`` of the ranks' payloads to ``dst``,
+    padded to the largest rank payload (flat uint8): RCCL has no variable-size gather; each peer sends
+    its block over its own xGMI link to ``dst`` and nothing is sent to the other ranks (an all_gather
+    would move world_size times the bytes).  Returns {video_id: tensor} on ``dst`` and {} elsewhere."""
     if not dist.is_initialized():
         return dict(results)
     rank, world = dist.get_rank(), dist.get_world_size()
     on_gpu = dist.get_backend() == 'nccl'
     dev = torch.device('cuda', torch.cuda.current_device()) if on_gpu else torch.device('cpu')
-    header = torch.zeros(n_videos, 4, dtype=torch.int64, device=dev)
+    header = torch.zeros(n_videos, 4, dtype=torch.int64)
     for v, t in results.items():
-        header[v] = torch.tensor([1, t.shape[0], t.shape[1], t.shape[2]], dtype=torch.int64, device=dev)
+        header[v] = torch.tensor([1, t.shape[0], t.shape[1], t.shape[2]], dtype=torch.int64)
+    header = header.to(dev)
     headers = [torch.zeros_like(header) for _ in range(world)]
     dist.all_gather(headers, header)
-    sizes = [int((h[:, 0] * h[:, 1] * h[:, 2] * h[:, 3]).sum()) for h in headers]
+    table = torch.stack(headers).cpu()                               # [world, n_videos, 4], one D2H copy
+    sizes = (table[:, :, 0] * table[:, :, 1] * table[:, :, 2] * table[:, :, 3]).sum(dim=1).tolist()
     cap = max(max(sizes), 1)
     payload = torch.zeros(cap, dtype=torch.uint8, device=dev)
     at = 0
@@ -112,16 +117,15 @@ def gather_label_maps(results, n_videos, dst=0):
         flat = results[v].to(dev).reshape(-1)
         payload[at:at + flat.numel()] = flat
         at += flat.numel()
-    payloads = [torch.zeros_like(payload) for _ in range(world)]
-    dist.all_gather(payloads, payload)
+    payloads = [torch.zeros_like(payload) for _ in range(world)] if rank == dst else None
+    dist.gather(payload, payloads, dst=dst)
     out = {}
     if rank == dst:
         for r in range(world):
             at = 0
-            h = headers[r]
             for v in range(n_videos):
-                if int(h[v, 0]):
-                    n, hh, ww = int(h[v, 1]), int(h[v, 2]), int(h[v, 3])
+                has, n, hh, ww = (int(x) for x in table[r, v])
+                if has:
                     out[v] = payloads[r][at:at + n * hh * ww].reshape(n, hh, ww).clone()
                     at += n * hh * ww
     return out

@@ -989,3 +989,28 @@ def test_bench_two_ranks_over_rccl():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['value'] > 0
+
+
+def test_sharded_runner_on_a_720p_multi_object_clip(oracle_mod):
+    """BASELINE configs[3] shape on one rank: a 720x1280, 3-object clip through
+    rmnet_amd.inference.segment_videos / evaluate_videos (flows from TinyFlowNet, frame loop, labels, J on
+    the device) == running the two networks by hand."""
+    from rmnet_amd import inference, metrics, networks
+    from rmnet_amd.synthetic import synthetic_clip
+    from rmnet_amd.tiny_flownet import TinyFlowNet
+    prod, _ = _nets(oracle_mod)
+    prod.fuse_epilogues()
+    tfn = networks.procedural_init_(TinyFlowNet(None)).to(dev()).eval().fuse_epilogues()
+    frames, masks, _, n_objects = synthetic_clip(4, 4, 720, 1280, seed=72, size=1.5)
+    video = {'frames': frames[0], 'masks': masks[0], 'n_objects': 3, 'labels': masks[0].argmax(0).to(torch.uint8)}
+    video['labels'] = masks[0].argmax(dim=1).to(torch.uint8)
+    seg = lambda v: inference.segment_video(prod, tfn, v, memorize_every=2)
+    with torch.no_grad():
+        got = inference.segment_videos([video], seg)
+        fr = frames.to(dev())
+        want = prod(fr, masks, tfn(fr), n_objects, 2)[0].argmax(1).to(torch.uint8)
+        j = inference.evaluate_videos([video], seg)
+    assert sorted(got) == [0] and got[0].shape == (4, 720, 1280) and got[0].is_cuda
+    assert (got[0] == want).float().mean() > 0.999
+    jj = metrics.jaccard_per_object(want.long(), video['labels'].to(dev()).long(), 3)[1:-1]
+    assert abs(j - float(jj.mean())) < 1e-3
