@@ -235,6 +235,7 @@ struct BArgs {
   float* ws_ml;              // [no][slots][2][kQT]: running reference (log2 domain) and sum
   int32_t* ws_plan;          // [no][kPlanInts]
   int T;
+  int trace_slot;            // BK_TRACE builds: the (unused) last partial slot receives the cycle stamps
   int gate;                  // != 0: do nothing when the bank's overflow word is set (mr_main then runs instead)
   int obj0, nobj;            // objects [obj0, obj0 + nobj) belong to this launch (nobj <= kMaxObj)
   int slot0, target;         // first partial slot of the launch; workgroups to aim for
@@ -336,7 +337,7 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
   const int l15 = lane & 15, g = lane >> 4;
   const int jt0 = wk.jt0, ntl = wk.ntl;
 #if BK_TRACE
-  long long* trc = reinterpret_cast<long long*>(a.ws_o + (size_t)(a.slot0 + a.target - 1) * (size_t)kDo * kQT);
+  long long* trc = reinterpret_cast<long long*>(a.ws_o + (size_t)a.trace_slot * (size_t)kDo * kQT);
   int trn = 0;
   const bool trace_on = blockIdx.x == 0 && wave == 0 && lane == 0;
   if (trace_on) trc[trn++] = t_entry;
@@ -368,6 +369,51 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
       }
   }
   float mref = -INFINITY, lsum = 0.0f;
+
+  // K ring feeding (was the consumers' job: its ~35 instructions sat on THEIR critical path -- a
+  // consumer's head issues slowly while the other waves' MFMAs own the SIMD's issue slots -- whereas a
+  // producer idles ~800 cycles per tile at the barrier).  A tile is one contiguous 8 KB block per plane
+  // = 512 chunks of 16 B; producer thread pt moves chunks pt and pt + 256 of both planes.  LDS image:
+  // row = cell (256 B), chunk c of row r stored at chunk c ^ (r & 15) -> the ds_read_b128 of the A
+  // fragments are conflict-free.
+  const size_t so0 = (size_t)o * b.Tcap;
+  const int pt = wave * 64 + lane;
+  const int prow = pt >> 4;
+  const int kdst = prow * 256 + (((pt & 15) ^ (prow & 15)) << 4);      // (row prow + 16: + 4096, same swizzle)
+  auto k_load = [&](half8 (&kr)[4], int tt, int ll) {
+    const size_t off = ((so0 + tt) * b.hwp + (size_t)ll * kJT) * kDe * sizeof(_Float16) + (size_t)pt * 16;
+    kr[0] = *reinterpret_cast<const half8*>(b.kh + off);
+    kr[1] = *reinterpret_cast<const half8*>(b.kh + off + 4096);
+    kr[2] = *reinterpret_cast<const half8*>(b.kl + off);
+    kr[3] = *reinterpret_cast<const half8*>(b.kl + off + 4096);
+  };
+  auto k_store = [&](const half8 (&kr)[4], int slot) {
+    char* d = Kl_ + slot * 2 * kKbuf + kdst;
+    *reinterpret_cast<half8*>(d) = kr[0];
+    *reinterpret_cast<half8*>(d + 4096) = kr[1];
+    *reinterpret_cast<half8*>(d + kKbuf) = kr[2];
+    *reinterpret_cast<half8*>(d + kKbuf + 4096) = kr[3];
+  };
+  half8 kr[4];                     // K tile n+5 on its way to the ring (one iteration to land)
+  Cursor ck;
+  ck.init(tpre, wk.t, jt0 + ntl - 1);
+  {
+    half8 k0[4], k1[4], k2[4], k3[4];
+    const int a0 = ck.seek(jt0);
+    k_load(k0, ck.tt, a0);
+    const int a1 = ck.seek(jt0 + 1);
+    k_load(k1, ck.tt, a1);
+    const int a2 = ck.seek(jt0 + 2);
+    k_load(k2, ck.tt, a2);
+    const int a3 = ck.seek(jt0 + 3);
+    k_load(k3, ck.tt, a3);
+    const int a4 = ck.seek(jt0 + 4);
+    k_load(kr, ck.tt, a4);
+    k_store(k0, 0);
+    k_store(k1, 1);
+    k_store(k2, 2);
+    k_store(k3, 3);
+  }
 
   struct Frags { half8 a0h[4], a1h[4], a0l[4], a1l[4]; };
   auto k_frags = [&](Frags& f, int kslot) {   // 16 conflict-free ds_read_b128 (XOR-swizzled rows)
@@ -440,8 +486,17 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
       const half2 h = {(_Float16)pv[2 * i], (_Float16)pv[2 * i + 1]};
       const unsigned hk = __builtin_bit_cast(unsigned, h);
       unsigned lk;   // lo = fp16(p - hi): fp32 subtract and one rounding, straight into its half
-      asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lk) : "v"(pv[2 * i]), "v"(hk));
-      asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lk) : "v"(pv[2 * i + 1]), "v"(hk));
+      // hipcc does not pad hazards around inline asm (cdna_hip_programming.md 5.7 item 2).  The inputs come
+      // straight from v_exp_f32 / v_cvt_pk (a transcendental result needs one wait state before a VALU reads
+      // it) and v_fma_mixhi reads the register v_fma_mixlo has just written with a destination half-select
+      // (one more): without the s_nops one producer wave occasionally published a wrong lo plane -- errors of
+      // ~5e-3 on 16 queries of one launch in thirty (tests/stress_race.py).
+      asm("s_nop 0\n\t"
+          "v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+          "s_nop 0\n\t"
+          "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+          "s_nop 0"
+          : "=&v"(lk) : "v"(pv[2 * i]), "v"(pv[2 * i + 1]), "v"(hk));
       ph[i] = hk;
       plo[i] = lk;
     }
@@ -480,10 +535,18 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
       __builtin_amdgcn_sched_barrier(0);             // MFMAs first (the pipe is idle right after a barrier)
 #endif
       BK_STAMP();   // MFMAs issued
+
       soft_max(sp0, sp1, nvalid, (n + 1) & 1);       // tile n+1
       BK_STAMP();   // soft-max done
       sp0 = s0; sp1 = s1;
       k_frags(f, kslot);                             // tile n+3: its LDS latency hides under the barrier
+      if (!(BK_ABLATE & 16)) {
+        // K ring: tile n+4 (requested one iteration ago) -> slot n%4, whose last reader (tile n) passed
+        // the barrier of iteration n-3; request tile n+5 (a clamped duplicate past the end: harmless)
+        k_store(kr, (kslot + 1) & 3);
+        const int l5 = ck.seek(jt0 + n + 5);
+        k_load(kr, ck.tt, l5);
+      }
     }
     kslot = (kslot + 1) & 3;
     BK_STAMP();   // S/soft-max done
@@ -508,27 +571,15 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
   const size_t so0 = (size_t)o * b.Tcap;
   const size_t tiles_per_slot = (size_t)(b.hwp / kJT);
 #if BK_TRACE
-  long long* trc = reinterpret_cast<long long*>(a.ws_o + (size_t)(a.slot0 + a.target - 1) * (size_t)kDo * kQT) + 1024;
+  long long* trc = reinterpret_cast<long long*>(a.ws_o + (size_t)a.trace_slot * (size_t)kDo * kQT) + 1024;
   int trn = 0;
-  const bool trace_on = blockIdx.x == 0 && wave == kProducers && lane == 0;
+#ifndef BK_TRACE_WAVE
+#define BK_TRACE_WAVE kProducers
+#endif
+  const bool trace_on = blockIdx.x == 0 && wave == BK_TRACE_WAVE && lane == 0;
   if (trace_on) trc[trn++] = t_entry;
 #endif
   BK_STAMP();
-  // K: a tile is one contiguous 8 KB block per plane = 512 consumer threads x 16 B.  LDS image:
-  // row = cell (256 B), 16-byte chunk c of row r stored at chunk c ^ (r & 15) -> the producers'
-  // ds_read_b128 of the A fragments are conflict-free.
-  const int ct = (wave - kProducers) * 64 + lane;
-  const int krow = ct >> 4;
-  const int kdst = krow * 256 + (((ct & 15) ^ (krow & 15)) << 4);
-  auto k_load = [&](half8 (&kr)[2], int tt, int ll) {
-    const size_t off = ((so0 + tt) * b.hwp + (size_t)ll * kJT) * kDe * sizeof(_Float16) + (size_t)ct * 16;
-    kr[0] = *reinterpret_cast<const half8*>(b.kh + off);
-    kr[1] = *reinterpret_cast<const half8*>(b.kl + off);
-  };
-  auto k_store = [&](const half8 (&kr)[2], int slot) {
-    *reinterpret_cast<half8*>(Kl_ + slot * 2 * kKbuf + kdst) = kr[0];
-    *reinterpret_cast<half8*>(Kl_ + slot * 2 * kKbuf + kKbuf + kdst) = kr[1];
-  };
   // V: fragment-ordered planes; this wave's first d-tile and its lane inside a tile's 32 KB plane
   const int dt0 = kCDT * (wave - kProducers);
   const size_t vlane = (size_t)(dt0 * 64 + lane) * 16;
@@ -539,24 +590,9 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
   // of the 8 consumers queue up in the CU's one address unit, 16 cycles each, while the matrix pipe
   // idles: that serial tail was 1/3 of a tile) and every load has one full iteration to land.
   half8 vh[kCDT], vl[kCDT];
-  half8 kr[2];                     // K tile n+5 on its way to the ring (one iteration to land)
-  Cursor ck, cv;
-  ck.init(tpre, wk.t, jt0 + ntl - 1);
+  Cursor cv;
   cv.init(tpre, wk.t, jt0 + ntl - 1);
   {
-    half8 k0[2], k1[2], k2[2], k3[2];
-    const int a0 = ck.seek(jt0);
-    k_load(k0, ck.tt, a0);
-    const int a1 = ck.seek(jt0 + 1);
-    k_load(k1, ck.tt, a1);
-    const int a2 = ck.seek(jt0 + 2);
-    k_load(k2, ck.tt, a2);
-    const int a3 = ck.seek(jt0 + 3);
-    k_load(k3, ck.tt, a3);
-    // same issue order as the steady state (K request, then the V fragments), so that the loop's
-    // counted waits are the same on entry as on the back edge
-    const int a4 = ck.seek(jt0 + 4);
-    k_load(kr, ck.tt, a4);
     const int l0 = cv.seek(jt0);
     const size_t off = v_tile(cv.tt, l0);
 #pragma unroll
@@ -564,10 +600,6 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
       vh[dt] = *reinterpret_cast<const half8*>(b.vh + off + dt * 1024);
       vl[dt] = *reinterpret_cast<const half8*>(b.vl + off + dt * 1024);
     }
-    k_store(k0, 0);
-    k_store(k1, 1);
-    k_store(k2, 2);
-    k_store(k3, 3);
   }
   f32x4 acc[kCDT][4];
 #pragma unroll
@@ -578,7 +610,6 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
   __syncthreads();                                   // B: P(0) visible
   BK_STAMP();
 
-  int kslot = 0;                                     // ring slot of tile n+4 (= n % 4)
   for (int n = 0; n < ntl; ++n) {
     const int buf = n & 1;
     BK_STAMP();   // loop top
@@ -590,13 +621,6 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
       bh[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + lane * 16);
       bl[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + 1024 + lane * 16);
     }
-    // K ring: tile n+4 (requested one iteration ago) -> slot n%4; request tile n+5
-    if (!(BK_ABLATE & 16)) {
-      k_store(kr, kslot);                            // (a clamped duplicate past the end: harmless)
-      const int l5 = ck.seek(jt0 + n + 5);
-      k_load(kr, ck.tt, l5);
-    }
-    kslot = (kslot + 1) & 3;
     const int l1 = cv.seek(jt0 + n + 1);             // refill source: tile n+1 (clamped past the end)
     const size_t noff = v_tile(cv.tt, l1);
     const char* nvh = b.vh + noff;
@@ -607,6 +631,9 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
 #pragma unroll
         for (int it = 0; it < 4; ++it) acc[dt][it] *= al[it];
     }
+#if BK_TRACE > 1
+    BK_STAMP();   // head done (P fragments requested, K ring fed, cursors advanced)
+#endif
     // ---- O += V P: 4 channel tiles x 4 query tiles x 3 split terms; the 4 query tiles between two
     //      uses of an accumulator keep the MFMAs independent
 #pragma unroll
@@ -627,6 +654,9 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
         vl[dt] = *reinterpret_cast<const half8*>(nvl + dt * 1024);
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE (the scheduler sinks them to the end)
+#if BK_TRACE > 1
+      BK_STAMP();   // channel tile done
+#endif
     }
     BK_STAMP();   // PV done
     __syncthreads();   // the one barrier per tile
@@ -879,6 +909,7 @@ int launch_bank_main(const BankReadArgs& m, hipStream_t st) {
   a.ws_o = m.ws_o; a.ws_ml = m.ws_ml; a.ws_plan = m.ws_plan;
   a.T = m.T;
   a.gate = m.gate;
+  a.trace_slot = m.slots - 1;
   a.qscale = 1.44269504088896341f / sqrtf((float)kDe) * kBankScale;   // (the un-scaling is kSraw in the soft-max)
   // Objects are planned together in groups of <= kMaxObj; a group's partial slots start at
   // bank_group_slot0() and hold at most target + nobj * (query tiles) segments.

@@ -1014,3 +1014,25 @@ def test_sharded_runner_on_a_720p_multi_object_clip(oracle_mod):
     assert (got[0] == want).float().mean() > 0.999
     jj = metrics.jaccard_per_object(want.long(), video['labels'].to(dev()).long(), 3)[1:-1]
     assert abs(j - float(jj.mean())) < 1e-3
+
+
+@pytest.mark.parametrize('no,T,h,w,reads', [(2, 3, 6, 10, 60), (5, 3, 9, 13, 60), (8, 5, 30, 54, 12)])
+def test_bank_read_is_repeatable(no, T, h, w, reads, oracle_mod):
+    """The same bank read many times: every read must equal the oracle.  A hazard-timing bug (an inline-asm
+    v_fma_mix reading a v_exp_f32 result one state too early) once made one producer wave publish a wrong
+    lo plane in a few launches out of a hundred -- a single passing read proves nothing about those
+    (tests/stress_race.py is the long version)."""
+    from rmnet_amd import ops
+    rng = np.random.RandomState(no * 7 + T)
+    mk, mv, qk, qv, mr, qr = _random_case(rng, no, T, h, w, regional=True)
+    mr[:, T - 1] = (0, w - 1, 0, h - 1)
+    qr[:] = (0, w - 1, 0, h - 1)
+    mk[:, :, T - 1, h - 1, w - 1] = qk[:, :, 2, 3] * 9.0
+    want, _ = oracle_mod.regional_memory_read(mk, mv, qk, qv, mr, qr)
+    bank = _fill_bank(ops, mk, mv, mr, capacity=T + 1)
+    qk_d, qv_d, qr_d = cu(qk), cu(qv), cu(qr)
+    bad = 0
+    for _ in range(reads):
+        got = bank.read(T, qk_d, qv_d, qr_d).cpu().numpy()
+        bad += not np.allclose(got, want, atol=MR_ATOL, rtol=MR_RTOL)
+    assert bad == 0, '%d of %d reads differ from the oracle' % (bad, reads)

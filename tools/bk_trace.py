@@ -24,7 +24,7 @@ ws = torch.zeros(nb, dtype=torch.uint8, device=dev)
 for _ in range(3):
     bank.read(T, qk, qv, rect, ws=ws)
 torch.cuda.synchronize()
-slots = 256
+slots = 256 + no * ((h * w + 1 + 63) // 64)      # bank_total_slots(): the stamps live in the last slot
 off = (slots - 1) * 512 * 64 * 4
 tr = ws[off:off + 2048 * 8].view(torch.int64).cpu().numpy()
 for name, a, labels in (('producer wave0', tr[:1024], ['top->MFMAs issued', 'soft-max', 'K frags', 'barrier', '->next top']),
