@@ -265,6 +265,9 @@ constexpr int kRThreads = 64 * (kProducers + kConsumers);  // 768 = 12 waves = 3
 #ifndef BK_SCHED
 #define BK_SCHED 1
 #endif
+#ifndef BK_VNT
+#define BK_VNT 0       // experiments only: non-temporal V fragment loads
+#endif
 #ifndef BK_CLK
 #define BK_CLK 0       // experiments only: per-workgroup shader-cycle / real-time stamps behind the plan records
 #endif
@@ -650,8 +653,13 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
         acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[dt], bh[it], acc[dt][it], 0, 0, 0);
 #endif
       if (!(BK_ABLATE & 1)) {   // this channel tile's fragments of the next tile, unconditionally
+#if BK_VNT
+        vh[dt] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(nvh + dt * 1024));
+        vl[dt] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(nvl + dt * 1024));
+#else
         vh[dt] = *reinterpret_cast<const half8*>(nvh + dt * 1024);
         vl[dt] = *reinterpret_cast<const half8*>(nvl + dt * 1024);
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE (the scheduler sinks them to the end)
 #if BK_TRACE > 1

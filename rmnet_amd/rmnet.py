@@ -99,7 +99,28 @@ class RMNet(nn.Module):
         self.eval()
         fuse_epilogues_(self, enable)
         self._fused_tail = bool(enable)     # decoder tail: rmnet_soft_aggregate_f32 (frame loop only)
+        self._fused_warp = None             # warp inside the box reduction: self-checked on first use
         return self
+
+    def _fused_warp_ok(self, device):
+        """The warp-fused box kernel reproduces, operation by operation, what THIS torch / ROCm build
+        executes for ``warp()`` (reciprocal multiply of the scalar division, grid_sampler's unnormalise,
+        FMA order, the 0.9999 validity test).  Another build could differ by one ulp and move a >= 0.5
+        decision, i.e. a box -- silently.  So the first use on a device compares one small random warp bit
+        for bit; on any difference the loop falls back to region_map(self.warp(...)) and says so."""
+        if self._fused_warp is None:
+            g = torch.Generator().manual_seed(1234)
+            m = torch.rand(1, 3, 37, 53, generator=g).to(device)
+            f = (torch.randn(1, 2, 37, 53, generator=g) * 6.0).to(device)
+            want = self.warp(m, f)[0].contiguous()
+            _, bb, _, got = ops.region_map(m, want_map=False, flow=f, want_warped=True)
+            _, bb0, _ = ops.region_map(want, want_map=False)
+            self._fused_warp = bool(torch.equal(got[:, 1:], want[:, 1:]) and torch.equal(bb, bb0))
+            if not self._fused_warp:
+                import warnings
+                warnings.warn('rmnet_amd: the warp-fused region kernel is not bit-identical to torch.grid_sample on this '
+                              'torch/ROCm build; using region_map(warp(...)) instead')
+        return self._fused_warp
 
     # ------------------------------------------------------------------ small helpers
     @staticmethod
@@ -289,7 +310,7 @@ class RMNet(nn.Module):
         T = bank.stage(k4.contiguous(), v4.contiguous(), rects.view(B * K, 4).index_select(0, ctx.flat))
         if commit:
             bank.commit()
-        if (getattr(self, '_fused_tail', False) and not self.training):             # warp fused into the box reduction
+        if getattr(self, '_fused_tail', False) and self._fused_warp_ok(prev_mask.device):   # warp fused into the box reduction
             _, _, q_rects = ops.region_map(prev_mask.contiguous(), want_map=False, flow=cur_flow.contiguous(),
                                            cell_grid=(ctx.lw, ctx.lh, 16, ctx.h, ctx.w))
         else:

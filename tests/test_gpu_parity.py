@@ -1036,3 +1036,24 @@ def test_bank_read_is_repeatable(no, T, h, w, reads, oracle_mod):
         got = bank.read(T, qk_d, qv_d, qr_d).cpu().numpy()
         bad += not np.allclose(got, want, atol=MR_ATOL, rtol=MR_RTOL)
     assert bad == 0, '%d of %d reads differ from the oracle' % (bad, reads)
+
+
+def test_fused_warp_self_check_and_fallback(oracle_mod):
+    """fuse_epilogues() arms a one-off bit-exactness check of the warp-fused box kernel against this build's
+    torch warp; when it fails the frame loop uses region_map(warp(...)) (forced here by patching warp)."""
+    from rmnet_amd.synthetic import synthetic_clip
+    prod, _ = _nets(oracle_mod)
+    prod.fuse_epilogues()
+    frames, masks, flows, n_objects = synthetic_clip(3, 2, 96, 160, seed=2, size=1.4)
+    with torch.no_grad():
+        a = prod(frames, masks, flows, n_objects, 1)
+    assert prod._fused_warp is True
+    prod.fuse_epilogues()                      # re-arm
+    orig = prod.warp
+    prod.warp = lambda img, flow: tuple(t + (1e-3 if i == 0 else 0) for i, t in enumerate(orig(img, flow)))
+    with pytest.warns(UserWarning, match='not bit-identical'):
+        assert prod._fused_warp_ok(dev()) is False
+    prod.warp = orig
+    with torch.no_grad():
+        b = prod(frames, masks, flows, n_objects, 1)      # un-fused warp path, same boxes
+    assert float((a - b).abs().max()) < 1e-5

@@ -1,0 +1,60 @@
+# -*- coding: utf-8 -*-
+"""Average FETCH_SIZE / WRITE_SIZE per launch from the rows tools/pmc_traffic.sh extracted, and the traffic
+file bench.py reads (profiles/bk_main_hbm_traffic.json, stamped with the kernel sources' hash).
+
+    python tools/pmc_traffic.py gpurun_out/pmc [--write-profile]
+
+Units: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB.  Calibration for THIS kernel's access pattern
+(16-byte-per-lane fragment loads): round 1 measured FETCH_SIZE 21467.9 KB against 21.5 MB of known input
+bytes on a dense single-object read -> factor 1.0 (the x2 correction MI355X_MICROARCH.md gives for wide
+streaming reads does not apply to this pattern); WRITE_SIZE 30069 KB vs 30.7 MB of partials -> factor 1.0."""
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def per_kernel(path):
+    out = {}
+    if not os.path.exists(path):
+        return out
+    for row in csv.reader(open(path)):
+        name = [c for c in row if 'rmnet::' in c]
+        if not name:
+            continue
+        short = name[0].split('::')[-1].split('(')[0].split('<')[0]
+        # columns: ..., Counter_Name, Counter_Value, Start, End
+        val = float(row[-3])
+        out.setdefault(short, []).append(val)
+    return {k: (sum(v) / len(v), len(v)) for k, v in out.items()}
+
+
+def main():
+    d = sys.argv[1]
+    fetch, write = per_kernel(os.path.join(d, 'FETCH_SIZE.csv')), per_kernel(os.path.join(d, 'WRITE_SIZE.csv'))
+    for k in sorted(set(fetch) | set(write)):
+        f, w = fetch.get(k, (0, 0)), write.get(k, (0, 0))
+        print('%-28s fetch %10.1f KB (%d launches)   write %10.1f KB (%d launches)' % (k, f[0], f[1], w[0], w[1]))
+    if '--write-profile' in sys.argv and 'bk_main' in fetch and 'bk_main' in write:
+        import bench
+        H, W, K, T = bench.H, bench.W, bench.K_CH, bench.T_MEM
+        abytes = bench.algorithmic_bytes(8 * (K - 1), T, 30, 54)
+        prof = {'kernel': 'bk_main', 'source_hash': bench.source_hash(),
+                'command': 'tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE (then WRITE_SIZE, separate pass) --kernel-trace -- '
+                           'python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extras (8 object-frames per launch)',
+                'fetch_size_kb_per_launch': round(fetch['bk_main'][0], 1), 'write_size_kb_per_launch': round(write['bk_main'][0], 1),
+                'hbm_bytes_per_launch': int(1024 * (fetch['bk_main'][0] + write['bk_main'][0])),
+                'algorithmic_bytes_per_launch': abytes,
+                'calibration': __doc__.split('Units:')[1].strip(),
+                'other_kernels_same_run': {k: {'fetch_size_kb_per_launch': round(fetch.get(k, (0, 0))[0], 1),
+                                               'write_size_kb_per_launch': round(write.get(k, (0, 0))[0], 1)}
+                                           for k in sorted(set(fetch) | set(write)) if k != 'bk_main'}}
+        json.dump(prof, open(os.path.join(ROOT, 'profiles', 'bk_main_hbm_traffic.json'), 'w'), indent=1)
+        print('wrote profiles/bk_main_hbm_traffic.json')
+
+
+if __name__ == '__main__':
+    main()
