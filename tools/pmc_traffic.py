@@ -11,6 +11,7 @@ streaming reads does not apply to this pattern); WRITE_SIZE 30069 KB vs 30.7 MB 
 import csv
 import json
 import os
+import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,7 +26,8 @@ def per_kernel(path):
         name = [c for c in row if 'rmnet::' in c]
         if not name:
             continue
-        short = name[0].split('::')[-1].split('(')[0].split('<')[0]
+        m = re.search(r'namespace\)::(\w+)', name[0])
+        short = m.group(1) if m else name[0][:40]
         # columns: ..., Counter_Name, Counter_Value, Start, End
         val = float(row[-3])
         out.setdefault(short, []).append(val)

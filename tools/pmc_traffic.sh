@@ -16,4 +16,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
   grep -E "bk_main|mr_combine|bk_append|region_reduce|region_fill|flow_affine|soft_aggregate" "$f" > $ROOT/gpurun_out/pmc/$c.csv || true
   tail -1 /tmp/pmc_$c.log | cut -c1-300
 done
-python $ROOT/tools/pmc_traffic.py $ROOT/gpurun_out/pmc
+python $ROOT/tools/pmc_traffic.py $ROOT/gpurun_out/pmc --write-profile && cp $ROOT/profiles/bk_main_hbm_traffic.json $ROOT/gpurun_out/pmc/
