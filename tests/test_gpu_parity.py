@@ -981,11 +981,17 @@ def test_bench_two_ranks_over_rccl():
     import sys
     if torch.cuda.device_count() < 2:
         pytest.skip('needs >= 2 GPUs (the test box has %d); the N > 1 path is covered by the gloo tests' % torch.cuda.device_count())
+    import socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')      # dmabuf IPC (the host driver has no legacy IPC)
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-                          '--master-addr', '127.0.0.1', '--master-port', '29517', os.path.join(root, 'bench.py'),
+                          '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'),
                           '--gpus', '2', '--steps', '2', '--warmup', '1', '--clips-per-gpu', '1', '--no-cpu-baseline'],
-                         capture_output=True, text=True, timeout=900, cwd=root)
+                         capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['value'] > 0
