@@ -1143,3 +1143,29 @@ def test_sharded_runner_two_ranks_on_real_kernels():
     assert sorted(maps0) == [0, 1, 2] and maps1 == {}
     assert maps0[0].shape == (3, 720, 1280) and maps0[1].shape == (4, 480, 854) and maps0[0].dtype == torch.uint8
     assert abs(j0 - j1) < 1e-12 and 0.0 <= j0 <= 1.0
+
+
+def test_bank_error_is_in_the_exact_fp32_kernels_class(oracle_mod):
+    """'fp32-class' made concrete: against the double-accumulating oracle, the split-fp16 bank read's largest
+    error stays within 2x the exact-fp32 MFMA kernel's largest error (+1e-7) on the same inputs -- over several
+    seeds, regional and dense, including a peaky soft-max (key scale 3)."""
+    from rmnet_amd import ops
+    worst = []
+    for seed, (no, T, h, w, regional, kq) in enumerate([(2, 3, 12, 20, True, 0.6), (1, 5, 30, 54, True, 0.6),
+                                                        (1, 2, 16, 24, False, 0.6), (2, 3, 12, 20, True, 3.0),
+                                                        (3, 4, 9, 13, True, 1.5)]):
+        rng = np.random.RandomState(900 + seed)
+        mk, mv, qk, qv, mr, qr = _random_case(rng, no, T, h, w, scale=kq, regional=regional)
+        if regional:
+            want, _ = oracle_mod.regional_memory_read(mk, mv, qk, qv, mr, qr)
+            exact, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), cu(mr), cu(qr), flags=ops.MR_EXACT_FP32)
+        else:
+            want, _ = oracle_mod.memory_read(mk, mv, qk, qv)
+            exact, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), flags=ops.MR_EXACT_FP32)
+        bank = _fill_bank(ops, mk, mv, mr)
+        got = bank.read(T, cu(qk), cu(qv), None if qr is None else cu(qr)).cpu().numpy()
+        e_bank = float(np.abs(got[:, :512] - want[:, :512]).max())
+        e_fp32 = float(np.abs(exact.cpu().numpy()[:, :512] - want[:, :512]).max())
+        worst.append((e_bank, e_fp32))
+        assert e_bank <= 2.0 * e_fp32 + 1e-7, (seed, e_bank, e_fp32)
+    assert max(e for e, _ in worst) < 5e-6
