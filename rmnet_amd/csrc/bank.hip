@@ -265,6 +265,9 @@ constexpr int kRThreads = 64 * (kProducers + kConsumers);  // 768 = 12 waves = 3
 #ifndef BK_SCHED
 #define BK_SCHED 1
 #endif
+#ifndef BK_YPRIO
+#define BK_YPRIO 0     // experiments only: static priority of the younger consumer waves (8-11)
+#endif
 #ifndef BK_VNT
 #define BK_VNT 0       // experiments only: non-temporal V fragment loads
 #endif
@@ -723,6 +726,9 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   const bool producer = wave < kProducers;
   if (a.gate && __builtin_amdgcn_readfirstlane(*b.ovf) != 0) return;   // out-of-window element: exact fp32 path runs
   if (producer && BK_PRIO > 0) __builtin_amdgcn_s_setprio(BK_PRIO);
+#if BK_YPRIO
+  if (wave >= kProducers + kConsumers / 2) __builtin_amdgcn_s_setprio(BK_YPRIO);   // experiment: the younger consumer of each SIMD
+#endif
 
   // ---- launch-wide plan, computed identically by every workgroup from the device-resident boxes
   //      (no host sync)
