@@ -1169,3 +1169,36 @@ def test_bank_error_is_in_the_exact_fp32_kernels_class(oracle_mod):
         worst.append((e_bank, e_fp32))
         assert e_bank <= 2.0 * e_fp32 + 1e-7, (seed, e_bank, e_fp32)
     assert max(e for e, _ in worst) < 5e-6
+
+
+def test_dropin_memory_read_is_graph_capturable(oracle_mod):
+    """rmnet_memory_read_f32's default path (memset of the overflow word, staging, gated bank read, gated exact
+    kernel, combine) captured into a HIP graph and replayed -- on clean inputs and, with the same graph, on inputs
+    that trip the device-side fallback."""
+    from rmnet_amd import ops
+    rng = np.random.RandomState(77)
+    mk, mv, qk, qv, mr, qr = _random_case(rng, 2, 3, 9, 13, regional=True)
+    mr[0, 1] = (0, 12, 0, 8)                                 # (the cell poisoned below lies inside its box)
+    d_mk, d_mv, d_qk, d_qv, d_mr, d_qr = cu(mk), cu(mv), cu(qk), cu(qv), cu(mr), cu(qr)
+    out = torch.empty(2, 1024, 9, 13, device=dev())
+    side = torch.cuda.Stream(dev())
+    side.wait_stream(torch.cuda.current_stream(dev()))
+    with torch.cuda.stream(side):
+        ops.memory_read(d_mk, d_mv, d_qk, d_qv, d_mr, d_qr, out=out)
+    torch.cuda.current_stream(dev()).wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        ops.memory_read(d_mk, d_mv, d_qk, d_qv, d_mr, d_qr, out=out)
+    out.zero_()
+    g.replay()
+    want, _ = oracle_mod.regional_memory_read(mk, mv, qk, qv, mr, qr)
+    np.testing.assert_allclose(out.cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL)
+    mv2 = mv.copy()
+    mv2[0, 3, 1, 2, 2] = 5e4                                 # out of the fp16 window: the replayed graph must fall back
+    d_mv.copy_(cu(mv2))
+    g.replay()
+    want2, _ = oracle_mod.regional_memory_read(mk, mv2, qk, qv, mr, qr)
+    np.testing.assert_allclose(out.cpu().numpy(), want2, atol=MR_ATOL, rtol=5e-5)
+    d_mv.copy_(cu(mv))                                       # and back to the fast path
+    g.replay()
+    np.testing.assert_allclose(out.cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL)
