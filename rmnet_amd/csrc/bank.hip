@@ -258,7 +258,8 @@ constexpr int kRThreads = 64 * (kProducers + kConsumers);  // 768 = 12 waves = 3
 #endif
 #ifndef BK_ABLATE
 #define BK_ABLATE 0    // experiments only, bit mask: 1 no V reloads, 2 no PV MFMAs, 4 no S/soft-max,
-#endif                 //                             8 no partial stores, 16 no K tile loads
+#endif                 //                             8 no partial stores, 16 no K tile loads, 32 / 64 cheaper soft-max
+                       //                             (changes the control flow: not a clean ablation), 128 a barrier every 2nd tile
 #ifndef BK_PRIO
 #define BK_PRIO 2
 #endif
@@ -556,6 +557,9 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
     }
     kslot = (kslot + 1) & 3;
     BK_STAMP();   // S/soft-max done
+#if BK_ABLATE & 128
+    if (n & 1)    // (experiment, wrong results: a barrier every second tile only -- how much is the coupling worth?)
+#endif
     __syncthreads();
     BK_STAMP();   // after barrier
   }
@@ -670,6 +674,9 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
 #endif
     }
     BK_STAMP();   // PV done
+#if BK_ABLATE & 128
+    if (n & 1)
+#endif
     __syncthreads();   // the one barrier per tile
     BK_STAMP();   // after barrier
   }
