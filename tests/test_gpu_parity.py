@@ -1202,3 +1202,22 @@ def test_dropin_memory_read_is_graph_capturable(oracle_mod):
     d_mv.copy_(cu(mv))                                       # and back to the fast path
     g.replay()
     np.testing.assert_allclose(out.cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL)
+
+
+def test_c_abi_from_a_native_client(tmp_path):
+    """The boundary is a C ABI, not a Python module: tests/native/capi_client.cpp (plain C++ + HIP runtime, no
+    torch, no Python, its own scalar host references) is compiled against include/rmnet_hip.h, linked with
+    librmnet_hip.so and run: region map, flow update (device and host-buffer entries), memory read (dense and
+    regional, default and exact-fp32 flags), and the error codes for a null pointer / a short workspace."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    exe = str(tmp_path / 'capi_client')
+    libdir = os.path.join(root, 'rmnet_amd')
+    cc = subprocess.run([hipcc, '-O2', '-std=c++17', '-w', os.path.join(root, 'tests', 'native', 'capi_client.cpp'),
+                         '-I' + os.path.join(root, 'include'), '-L' + libdir, '-lrmnet_hip', '-Wl,-rpath,' + libdir, '-o', exe],
+                        capture_output=True, text=True, timeout=600)
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and 'all ops OK' in run.stdout, (run.returncode, run.stdout[-1000:], run.stderr[-1000:])
