@@ -1119,7 +1119,7 @@ def _sharded_720p_worker(rank, world, port, q):
     with torch.no_grad():
         maps = inference.segment_videos(videos, seg)
         j = inference.evaluate_videos(videos, seg)
-    q.put((rank, len(seen) // 2, {k: v.cpu() for k, v in maps.items()}, j))
+    q.put((rank, len(seen) // 2, {k: v.cpu().numpy() for k, v in maps.items()}, j))   # (by value: the sender may exit first)
     dist.destroy_process_group()
 
 
@@ -1141,7 +1141,7 @@ def test_sharded_runner_two_ranks_on_real_kernels():
     (_, n0, maps0, j0), (_, n1, maps1, j1) = out
     assert n0 + n1 == 3 and n0 >= 1 and n1 >= 1               # (the 720p 3-object clip alone outweighs the other two)
     assert sorted(maps0) == [0, 1, 2] and maps1 == {}
-    assert maps0[0].shape == (3, 720, 1280) and maps0[1].shape == (4, 480, 854) and maps0[0].dtype == torch.uint8
+    assert maps0[0].shape == (3, 720, 1280) and maps0[1].shape == (4, 480, 854) and maps0[0].dtype == np.uint8
     assert abs(j0 - j1) < 1e-12 and 0.0 <= j0 <= 1.0
 
 
