@@ -125,6 +125,31 @@ def regional_memory_read(m_key, m_val, q_key, q_val, mem_rects, qry_rects, want_
     return memory_read(mk, mv, qk, qv, want_p)
 
 
+def memory_read_sampled(m_key, m_val, q_key, qidx):
+    """The read-out rows of ``memory_read`` for the query cells ``qidx`` (flat indices into h*w, the
+    same list for every object) only: [no, len(qidx), Do].  Same arithmetic, element for element
+    (rmnet_oracle.c); lets full-size cases (720p, T = 20) be checked in seconds."""
+    m_key, m_val, q_key = map(_f32, (m_key, m_val, q_key))
+    no, De, T, h, w = m_key.shape
+    Do = m_val.shape[1]
+    qi = np.ascontiguousarray(qidx, dtype=np.int32)
+    out = np.empty((no, qi.size, Do), dtype=np.float32)
+    lib().oracle_memory_read_sampled_f32(_p(m_key), _p(m_val), _p(q_key), no, De, Do, T, h, w,
+                                         _p(qi, ctypes.c_int32), int(qi.size), _p(out))
+    return out
+
+
+def regional_memory_read_sampled(m_key, m_val, q_key, mem_rects, qry_rects, qidx):
+    """``regional_memory_read`` on a sample of query cells (see ``memory_read_sampled``)."""
+    no = m_key.shape[0]
+    T = m_key.shape[2]
+    mr = np.asarray(mem_rects, dtype=np.int32).reshape(no, T, 4)
+    qr = np.asarray(qry_rects, dtype=np.int32).reshape(no, 1, 4)
+    mk, mv = rect_mask(m_key, mr), rect_mask(m_val, mr)
+    qk = rect_mask(np.asarray(q_key)[:, :, None], qr)[:, :, 0]
+    return memory_read_sampled(mk, mv, qk, qidx)
+
+
 def flow_affine(flow, m1, m2):
     """flow [H,W,2] f32, m1/m2 [2,3] f32 -> [H,W,2] f32."""
     flow, m1, m2 = _f32(flow), _f32(m1), _f32(m2)

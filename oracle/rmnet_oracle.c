@@ -208,6 +208,67 @@ void oracle_memory_read_f32(const float *m_key, const float *m_val, const float 
 }
 
 /* ---------------------------------------------------------------------------------
+ * M1 on a SAMPLE of query cells: the same arithmetic as oracle_memory_read_f32 (same
+ * accumulation order per element: channels ascending in a double accumulator, then the fp32
+ * roundings of :155-:157, :160), for the query cells qidx[0..nq) of every object only, so that
+ * BASELINE configs[4] (720p, T = 20: 72,000 memory cells x 3,600 query cells per object) can be
+ * checked against the oracle in seconds.  The loops over memory cells are unit-stride here (the
+ * full version walks a channel-strided column per cell), which changes no result.
+ * out [no][nq][Do]: the read-out rows (the q_val half of the cat is a copy, not sampled).
+ * tests/test_oracle.py checks this function bit for bit against oracle_memory_read_f32.
+ * ------------------------------------------------------------------------------- */
+void oracle_memory_read_sampled_f32(const float *m_key, const float *m_val, const float *q_key,
+                                    int no, int De, int Do, int T, int h, int w,
+                                    const int32_t *qidx, int nq, float *out) {
+  const size_t hw = (size_t)h * w, thw = (size_t)T * hw;
+  const float sqrt_de = sqrtf((float)De);
+  for (int o = 0; o < no; ++o) {
+    const float *mk = m_key + (size_t)o * De * thw;
+    const float *mv = m_val + (size_t)o * Do * thw;
+    const float *qk = q_key + (size_t)o * De * hw;
+#pragma omp parallel
+    {
+      double *acc = (double *)malloc(sizeof(double) * thw);
+      float *col = (float *)malloc(sizeof(float) * thw);
+#pragma omp for schedule(dynamic, 1)
+      for (int n = 0; n < nq; ++n) {
+        const size_t i = (size_t)qidx[n];
+        for (size_t j = 0; j < thw; ++j) acc[j] = 0.0;
+        for (int c = 0; c < De; ++c) {
+          const double q = (double)qk[(size_t)c * hw + i];
+          const float *k = mk + (size_t)c * thw;
+          for (size_t j = 0; j < thw; ++j) acc[j] += (double)k[j] * q;
+        }
+        float mx = -INFINITY;
+        for (size_t j = 0; j < thw; ++j) {
+          float s = (float)acc[j]; /* :155 */
+          s = s / sqrt_de;         /* :156 */
+          col[j] = s;
+          if (s > mx) mx = s;
+        }
+        double sum = 0.0;
+        for (size_t j = 0; j < thw; ++j) { /* :157 */
+          const float e = expf(col[j] - mx);
+          col[j] = e;
+          sum += (double)e;
+        }
+        const float fsum = (float)sum;
+        for (size_t j = 0; j < thw; ++j) col[j] = col[j] / fsum;
+        float *dst = out + ((size_t)o * nq + n) * Do;
+        for (int d = 0; d < Do; ++d) { /* :160 */
+          const float *v = mv + (size_t)d * thw;
+          double a = 0.0;
+          for (size_t j = 0; j < thw; ++j) a += (double)v[j] * (double)col[j];
+          dst[d] = (float)a;
+        }
+      }
+      free(acc);
+      free(col);
+    }
+  }
+}
+
+/* ---------------------------------------------------------------------------------
  * F1: updateOpticalFlow.  flow_affine_transformation.cpp:63-83.
  * flow [H,W,2] f32, m1/m2 [2,3] f32 -> out [H,W,2] f32.  All arithmetic is IEEE fp32,
  * one rounding per operation, evaluated left to right exactly as the reference's

@@ -33,8 +33,16 @@
 //             channels x all 64 queries each, with the V A-fragments loaded straight from the bank
 //             into registers (16 B / lane, no LDS, no transpose) one tile ahead, and feed the K
 //             ring.  ONE barrier per 32-cell tile.
-// bk_combine: (memory_read.hip's mr_combine, shared) merges the splits, adds the closed-form term
-//             for the masked memory cells, scatters to query cells, appends q_val * box.
+//             The SAME launch also does everything else of MemoryReader.forward: while a workgroup waits for
+//             the first dependent loads of its plan it streams its share of the soft-max-independent
+//             outputs -- the q_val half of the cat (x box) and the read-out of MASKED query cells (= the
+//             mean of m_val over all T*h*w cells, from the per-slot column sums bk_append leaves in the
+//             bank) -- and when a workgroup finishes a segment it publishes its partial (O, m, l) with
+//             write-through stores and draws a ticket; the last arriver of an (object, query tile) pair
+//             merges the pair's partials, adds the closed-form term of the masked memory cells,
+//             normalises and scatters the read-out to the query cells.  No combine kernel, no second pass
+//             over the partials by another launch.
+// bk_colsum : finishes a slot's column sums of the values (fixed summation order: reads are repeatable).
 #include "common.h"
 
 namespace rmnet {
@@ -43,7 +51,7 @@ namespace {
 constexpr int kDe = 128, kDo = 512;
 constexpr int kQT = 64, kJT = 32;
 constexpr int kThreads = 256;
-constexpr int kMaxT = 512;
+constexpr int kMaxT = 2048;   // memorised frames per read (LDS: tile prefix + cells per frame, 16 KB)
 constexpr float kDeferLog2 = 11.5415603f;   // 8 * log2(e): P <= e^8 stays far inside fp16 range (65504)
 // The S accumulators are in RAW units: keys are stored times 2^6 and the query fragments carry
 // log2(e) / sqrt(De) times 2^6 as well (both operands then sit where fp16's hi AND lo planes are
@@ -101,6 +109,9 @@ __host__ __device__ inline int kperm(int j) {
 
 }  // namespace
 
+namespace {
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+}
 BankView bank_view(void* base, int no, int Tcap, int h, int w) {
   BankView b;
   b.no = no; b.Tcap = Tcap; b.h = h; b.w = w; b.hw = h * w;
@@ -112,16 +123,28 @@ BankView bank_view(void* base, int no, int Tcap, int h, int w) {
   b.kl = p; p += kplane;
   b.vh = p; p += vplane;
   b.vl = p; p += vplane;
+  b.vpart = reinterpret_cast<float*>(p);
+  p += align256((size_t)no * Tcap * (b.hwp / kJT) * kDo * sizeof(float));
+  b.colsum = reinterpret_cast<float*>(p);
+  p += align256((size_t)no * Tcap * kDo * sizeof(float));
   b.area = reinterpret_cast<int32_t*>(p);
-  p += ((size_t)no * Tcap * 4 + 255) & ~(size_t)255;
-  b.ovf = reinterpret_cast<int32_t*>(p);
+  p += align256((size_t)no * Tcap * 4);
+  b.ovf = reinterpret_cast<int32_t*>(p);            // control block: overflow word, then the arrival tickets
+  b.cnt = reinterpret_cast<int32_t*>(p + 256);
   return b;
 }
+
+size_t bank_ctl_bytes(int no, int h, int w) { return 256 + align256((size_t)no * bank_nqt_max(h * w) * 4); }
 
 size_t bank_bytes(int no, int Tcap, int h, int w) {
   const size_t hwp = ((size_t)h * w + kJT - 1) / kJT * kJT;
   return 2 * (size_t)no * Tcap * hwp * kDe * 2 + 2 * (size_t)no * Tcap * kDo * hwp * 2 +
-         (((size_t)no * Tcap * 4 + 255) & ~(size_t)255) + 256;   // + the overflow word
+         align256((size_t)no * Tcap * (hwp / kJT) * kDo * 4) + align256((size_t)no * Tcap * kDo * 4) +
+         align256((size_t)no * Tcap * 4) + bank_ctl_bytes(no, h, w);
+}
+
+size_t bank_area_offset(int no, int Tcap, int h, int w) {
+  return bank_bytes(no, Tcap, h, w) - bank_ctl_bytes(no, h, w) - align256((size_t)no * Tcap * 4);
 }
 
 namespace {
@@ -205,6 +228,12 @@ __global__ __launch_bounds__(kThreads) void bk_append(BankView b, int slot0, int
         tile[p][c] = valid ? vb[(size_t)(c0 + c) * v_cs] : 0.0f;
       }
       __syncthreads();
+      if (tid < kDe) {   // this tile's column sums (cells in ascending order; padding cells are 0): the read-out of a
+        float sum = 0.0f;   // masked query cell is the mean of m_val over ALL cells (bk_main's static part)
+#pragma unroll 8
+        for (int j = 0; j < kJT; ++j) sum += tile[j][tid];
+        b.vpart[((so * (size_t)(b.hwp / kJT) + u) * kDo) + c0 + tid] = sum;
+      }
 #pragma unroll
       for (int i = 0; i < kDe / 64; ++i) {
         const int dl = (tid >> 2) + 64 * i, d = c0 + dl;
@@ -226,11 +255,23 @@ __global__ __launch_bounds__(kThreads) void bk_append(BankView b, int slot0, int
   }
 }
 
+// grid = no * nf blocks of kDo threads: slot (o, slot0 + f)'s column sums = its tiles' sums in tile order.
+__global__ __launch_bounds__(kDo) void bk_colsum(BankView b, int slot0, int nf) {
+  const int o = (int)blockIdx.x / nf, f = (int)blockIdx.x - o * nf, d = threadIdx.x;
+  const size_t so = (size_t)o * b.Tcap + slot0 + f;
+  const int ntiles = (b.area[so] + kJT - 1) / kJT;
+  const float* __restrict__ src = b.vpart + so * (size_t)(b.hwp / kJT) * kDo + d;
+  float sum = 0.0f;
+  for (int u = 0; u < ntiles; ++u) sum += src[(size_t)u * kDo];
+  b.colsum[so * kDo + d] = sum;
+}
+
 // ------------------------------------------------------------------------------------------ read
 struct BArgs {
   BankView b;
   const float *qk, *qv;
   const int32_t* qry_rects;  // [no][4] or null
+  float* out;                // [no][2 * kDo][h][w]: read-out, then q_val x box (models/rmnet.py:163)
   float* ws_o;               // [no][slots] partial blocks in fragment order (common.h)
   float* ws_ml;              // [no][slots][2][kQT]: running reference (log2 domain) and sum
   int32_t* ws_plan;          // [no][kPlanInts]
@@ -338,7 +379,8 @@ struct Cursor {
 // The S MFMAs of tile n+2 and the soft-max VALU chain of tile n+1 are independent, so inside the
 // producer wave the matrix pipe and the VALU overlap instead of running one after the other.
 __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
-                                     const int* tpre, const int* tarea, int wave, int lane, long long t_entry) {
+                                     const int* tpre, const int* tarea, int wave, int lane, long long t_entry,
+                                     float& m_out, float& l_out) {
   const BankView& b = a.b;
   const int o = wk.o;
   const int l15 = lane & 15, g = lane >> 4;
@@ -563,17 +605,15 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
     __syncthreads();
     BK_STAMP();   // after barrier
   }
-  if (g == 0 && !(BK_ABLATE & 8)) {
-    float* wm = a.ws_ml + (size_t)wk.slot * 2 * kQT;
-    wm[wave * 16 + l15] = mref * kSraw;                // log2 domain for the combine
-    wm[kQT + wave * 16 + l15] = lsum;
-  }
+  m_out = mref * kSraw;                                // log2 domain; the segment's epilogue takes it from here
+  l_out = lsum;
   BK_STAMP();
 }
 
 // ---------------------------------------------------------------- consumers: O += V P, K ring
 __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
-                                     const int* tpre, int wave, int lane, long long t_entry) {
+                                     const int* tpre, int wave, int lane, long long t_entry,
+                                     f32x4 (&acc)[kCDT][4]) {
   const BankView& b = a.b;
   const int o = wk.o;
   const int l15 = lane & 15, g = lane >> 4;
@@ -611,7 +651,6 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
       vl[dt] = *reinterpret_cast<const half8*>(b.vl + off + dt * 1024);
     }
   }
-  f32x4 acc[kCDT][4];
 #pragma unroll
   for (int dt = 0; dt < kCDT; ++dt)
 #pragma unroll
@@ -682,19 +721,6 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
   }
   BK_STAMP();
 
-  // ---- partial O -> workspace slot L in fragment order (common.h): 1 KB contiguous per store
-  if (!(BK_ABLATE & 8)) {
-    float* wo = a.ws_o + (size_t)wk.slot * (size_t)kDo * kQT;
-#pragma unroll
-    for (int dt = 0; dt < kCDT; ++dt)
-#pragma unroll
-      for (int it = 0; it < 4; ++it)
-        *reinterpret_cast<f32x4*>(wo + partial_frag_offset(dt0 + dt, it, lane)) = acc[dt][it];
-  }
-#if BK_TRACE
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-  BK_STAMP();   // epilogue stores drained
 }
 
 constexpr int kMaxObj = kBankMaxObj;    // objects planned together in one launch (the launcher groups more)
@@ -921,7 +947,7 @@ int launch_bank_stage(void* bank, int no, int Tcap, int h, int w, int slot0, int
   return check_launch();
 }
 
-size_t bank_overflow_offset(int no, int Tcap, int h, int w) { return bank_bytes(no, Tcap, h, w) - 256; }
+size_t bank_overflow_offset(int no, int Tcap, int h, int w) { return bank_bytes(no, Tcap, h, w) - bank_ctl_bytes(no, h, w); }
 
 int launch_bank_main(const BankReadArgs& m, hipStream_t st) {
   BArgs a;

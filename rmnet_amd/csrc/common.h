@@ -111,12 +111,16 @@ int launch_memory_read(const MemReadArgs& a, hipStream_t st);
 struct BankView {
   char *kh, *kl;   // [no][Tcap][hwp][128] fp16 hi / lo  (cell-major keys)
   char *vh, *vl;   // [no][Tcap][512][hwp] fp16 hi / lo  (channel-major values, cells permuted per 32)
+  float* vpart;    // [no][Tcap][hwp/32][512] fp32: per 32-cell tile, the sum of the (un-scaled) values of its cells
+  float* colsum;   // [no][Tcap][512] fp32: sum of a slot's values over the cells inside its box (bk_colsum)
   int32_t* area;   // [no][Tcap] cells inside the box of each memorised frame
   int32_t* ovf;    // number of 16-byte groups written so far that held an element outside fp16's window
+  int32_t* cnt;    // [no][nqt_max] arrival tickets of the partials of an (object, query tile) pair; zero between reads
   int no, Tcap, h, w, hw, hwp;
 };
 BankView bank_view(void* base, int no, int Tcap, int h, int w);
 size_t bank_bytes(int no, int Tcap, int h, int w);
+size_t bank_area_offset(int no, int Tcap, int h, int w);
 constexpr float kBankValueUnscale = 1.0f / 64.0f;   // values are stored times 2^6 (bank.hip)
 
 // Split heuristic shared by the read kernels and the combine kernel (must agree exactly).
@@ -144,14 +148,10 @@ __host__ __device__ inline BankPlan bank_plan(int Mq, int hw, int njt, int no, i
   return p;
 }
 
-// Plan record written by a read kernel for the combine kernel (one small load instead of re-deriving
-// the plan from rectangles / areas), 12 ints per object:
-//   mode 0 (mr_main):  {Mq, nqt, nsplit, M, qr.cx0, qr.cx1, qr.cy0, qr.cy1, first partial slot of the
-//                       object, 0, 0, 0}; the partial of (split s, query tile qt) is slot first + s * nqt + qt;
-//   mode 1 (bk_main):  {Mq, nqt, njt, M, qr.cx0, qr.cx1, qr.cy0, qr.cy1, first partial slot sb of the
-//                       object, chunk length C, 0, 1}; slots of pair (o, qt), see bank_chunks():
-//                       sb + blk * nqt + qt            for the nfull aligned column blocks, then
-//                       sb + nqt * nfull + chunk + qt  for the remainder chunks that touch the pair.
+// Plan record, 12 ints per object.  mr_main writes it for mr_combine (one small load instead of re-deriving the
+// plan from the rectangles): {Mq, nqt, nsplit, M, qr.cx0, qr.cx1, qr.cy0, qr.cy1, first partial slot of the
+// object, 0, 0, 0}; the partial of (split s, query tile qt) is slot first + s * nqt + qt.  bk_main merges its
+// partials itself and leaves {Mq, nqt, njt, M, qr..., first partial slot, chunk length C, 0, 1} for tools only.
 constexpr int kPlanInts = 12;
 
 // Chunking of one object's nqt x njt tile matrix into workgroup chunks of cost C (bank.hip):
@@ -184,7 +184,8 @@ __host__ __device__ inline int bank_chunk_min(int njt_max) {
 // Partial slots of a bank read.  Objects are planned in groups of kBankMaxObj per launch; a group of n
 // objects needs at most kSplitTargetSlots chunks + n * nqt_max pair boundaries.
 constexpr int kBankMaxObj = 64;
-__host__ __device__ inline int bank_nqt_max(int hw) { return (hw + 1 + 63) / 64; }
+__host__ __device__ inline int bank_nqt_max(int hw) { return (hw + 63) / 64; }   // (the bank read has no mean slot: masked
+                                                                                // query cells are filled from the slots' column sums)
 __host__ __device__ inline int bank_group_slot0(int obj0, int hw) {
   return (obj0 / kBankMaxObj) * (kSplitTargetSlots + kBankMaxObj * bank_nqt_max(hw));
 }
@@ -194,7 +195,7 @@ __host__ __device__ inline int bank_total_slots(int no, int hw) {
 }
 
 struct BankReadArgs {
-  const void* bank;
+  void* bank;
   int no, Tcap, h, w, T;
   const float *qk, *qv;
   const int32_t* qry_rects;
@@ -213,9 +214,9 @@ int launch_bank_stage(void* bank, int no, int Tcap, int h, int w, int slot0, int
                       const float* v4, long long k_cs, long long k_os, long long v_cs, long long v_os,
                       const int32_t* rects, hipStream_t st);   // nf frames of a strided [no,C,T,h,w] source
 size_t bank_overflow_offset(int no, int Tcap, int h, int w);
-int launch_bank_main(const BankReadArgs& a, hipStream_t st);   // bank.hip: the read kernel only
+int launch_bank_main(const BankReadArgs& a, hipStream_t st);   // bank.hip: the whole read (one launch per 64 objects)
 size_t bank_read_ws_bytes(int no, int h, int w);
-int launch_bank_read(BankReadArgs& a, hipStream_t st);         // memory_read.hip: main + combine
+int launch_bank_read(BankReadArgs& a, hipStream_t st);         // memory_read.hip: workspace carving + launch_bank_main
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? RMNET_OK : RMNET_E_LAUNCH; }
 

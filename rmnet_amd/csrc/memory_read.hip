@@ -52,7 +52,7 @@ constexpr int kJT = 32;          // memory cells per tile
 constexpr int kKS = 48;          // K tile row stride (floats): 32 + 16 -> lane groups on disjoint banks
 constexpr int kVS = 34;          // V tile row stride: 16 rows x {0,1} -> 32 distinct banks
 constexpr int kPS = 80;          // P tile row stride
-constexpr int kMaxT = 512;
+constexpr int kMaxT = 2048;       // memorised frames per read (LDS prefix array); models/rmnet.py:416-426 has no bound
 constexpr int kMaxSplits = kSplitMax;
 constexpr int kTargetSlots = kSplitTargetSlots;
 constexpr float kDefer = 30.0f;
@@ -863,10 +863,19 @@ int launch_memory_read(const MemReadArgs& m, hipStream_t st) {
       r.ws = nullptr; r.ws_bytes = 0; r.gate = 1;
       if (int e = launch_bank_main(r, st)) return e;
     }
-    if (regional)
-      hipLaunchKernelGGL(mr_main<true>, g1, dim3(kThreads), 0, st, a);
-    else
-      hipLaunchKernelGGL(mr_main<false>, g1, dim3(kThreads), 0, st, a);
+    {
+      // mr_main walks the COMPACTED cell list of the fp32 tensors (ceil(M / 32) tiles); the transient bank's
+      // per-frame tile count (sum_t ceil(area_t / 32), what bk_main walks) must not leak into its plan: with
+      // small boxes a split would start beyond the last cell (-inf - -inf = NaN).  Only the combine needs
+      // bank_area (log2-domain partials of bk_main).
+      KArgs am = a;
+      am.bank_area = nullptr;
+      am.bank_tcap = 0;
+      if (regional)
+        hipLaunchKernelGGL(mr_main<true>, g1, dim3(kThreads), 0, st, am);
+      else
+        hipLaunchKernelGGL(mr_main<false>, g1, dim3(kThreads), 0, st, am);
+    }
     if (int e = check_launch()) return e;
     if (m.ev_mid && hipEventRecord(m.ev_mid, st) != hipSuccess) return RMNET_E_LAUNCH;
     if (regional)

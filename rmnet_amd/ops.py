@@ -17,7 +17,7 @@ from . import _lib
 
 MR_FORCE_GENERIC = 1     # include/rmnet_hip.h RMNET_MR_*
 MR_EXACT_FP32 = 2
-BANK_MAX_SLOTS = 512     # csrc/bank.hip kMaxT
+BANK_MAX_SLOTS = 2048    # csrc/bank.hip, csrc/memory_read.hip kMaxT
 
 
 def _check(t, name, dtype=torch.float32):

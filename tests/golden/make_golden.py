@@ -13,6 +13,11 @@ are pre-seeded in ``sys.modules``:
   the *rest* of the path against the reference; the region map itself is pinned by the
   hand-computed known-answer file ``region_map_kat.json`` (written by hand, not by this script).
 
+``region_fuzz`` does the same for the kernel's loosen / clamp / point-count branches (.cu:55-77): the reference's box finder
+gives the tight boxes of 40 seeded masks whose box edges sit at, just before and just after every switching distance; the
+tests apply the four clamp expressions themselves (cases.boxes_after_loosen) for every (n_bbox_loose_pixels,
+n_pts_threshold) of cases.REGION_FUZZ_LOOSE x REGION_FUZZ_NPTS, independently of oracle/rmnet_oracle.c.
+
 ``flow_affine`` vectors come from the reference's own C++ compiled by oracle/Makefile
 (oracle/_ref/flow_affine_transformation.so).
 
@@ -221,6 +226,30 @@ def section_region_boxes(ref_rmnet, ref_tfn, ref_helpers, rng):
     np.savez_compressed(os.path.join(HERE, 'region_boxes.npz'), **out)
 
 
+def section_region_fuzz(ref_rmnet, ref_tfn, ref_helpers, rng):
+    # ---------------------------------------------------------------- region map loosen / clamp / count branches (G1)
+    # Reference side of the fuzz (tests/golden/cases.py: region_fuzz_case): the REFERENCE's own box finder on the
+    # thresholded masks + the number of above-threshold pixels (what .cu:41-42 counts); the clamp expressions of
+    # .cu:55-77 are evaluated by the tests on these (cases.boxes_after_loosen) -- rmnet_oracle.c is not involved.
+    import cases
+    out = {}
+    for i, (B, K, H, W) in enumerate(cases.REGION_FUZZ_SHAPES):
+        m = cases.region_fuzz_case(i)
+        tight = np.full((B * K, 4), -1, np.int32)
+        npts = np.zeros(B * K, np.int32)
+        for b in range(B):
+            for k in range(K):
+                hit = m[b, k] >= np.float32(0.5)
+                npts[b * K + k] = int(hit.sum())
+                bb = ref_helpers.get_bounding_boxes(hit)
+                if bb[0] is not None:
+                    tight[b * K + k] = [int(v) for v in bb]
+        out['case%02d.tight' % i] = tight
+        out['case%02d.npts' % i] = npts
+        out['case%02d.checksum' % i] = np.float64(m.astype(np.float64).sum())
+    np.savez_compressed(os.path.join(HERE, 'region_fuzz.npz'), **out)
+
+
 def section_msi(ref_rmnet, ref_tfn, ref_helpers, rng):
     # ---------------------------------------------------------------- multi_scale_inference (H1)
     import cases
@@ -252,7 +281,7 @@ WRITE = set()      # sections whose files are rewritten by this run
 
 SECTIONS = [('memory_reader', section_memory_reader), ('flow_affine', section_flow_affine), ('pad', section_pad),
             ('clip', section_clip), ('tiny_flownet', section_tiny_flownet), ('region_boxes', section_region_boxes),
-            ('msi', section_msi)]
+            ('region_fuzz', section_region_fuzz), ('msi', section_msi)]
 
 
 def main(argv):

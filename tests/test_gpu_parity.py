@@ -1221,3 +1221,144 @@ def test_c_abi_from_a_native_client(tmp_path):
     assert cc.returncode == 0, cc.stderr[-2000:]
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0 and 'all ops OK' in run.stdout, (run.returncode, run.stdout[-1000:], run.stderr[-1000:])
+
+
+# ----------------------------------------------------------------------------- round 3: remaining parity holes
+def test_region_map_loosen_clamp_count_branches_vs_reference_boxes(golden_dir):
+    """G1's point-count fallback and four clamp expressions (reg_att_map_generator.cu:55-77) on the GPU against
+    expectations that do not involve oracle/rmnet_oracle.c: the reference's own box finder (utils/helpers.py:93-102,
+    run by tests/golden/make_golden.py section region_fuzz) + the .cu's expressions restated in
+    tests/golden/cases.py:boxes_after_loosen, for n_bbox_loose_pixels in {0, 1, 63, 64, 65} x n_pts_threshold in
+    {1, 9, 10, 11} on 40 masks with box edges at / before / after every switching distance."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import cases
+    from rmnet_amd import ops
+    g = np.load(os.path.join(golden_dir, 'region_fuzz.npz'))
+    assert len(cases.REGION_FUZZ_SHAPES) == 40
+    for i, (B, K, H, W) in enumerate(cases.REGION_FUZZ_SHAPES):
+        m = cases.region_fuzz_case(i)
+        assert float(m.astype(np.float64).sum()) == float(g['case%02d.checksum' % i])
+        md = cu(m)
+        for L in cases.REGION_FUZZ_LOOSE:
+            for npt in cases.REGION_FUZZ_NPTS:
+                want = cases.boxes_after_loosen(g['case%02d.tight' % i], g['case%02d.npts' % i], K, H, W, npt, L).reshape(B, K, 4)
+                att, bb, _ = ops.region_map(md, 0.5, npt, L)
+                assert np.array_equal(bb.cpu().numpy(), want), (i, L, npt)
+                a = att.cpu().numpy()
+                for b in range(B):
+                    assert not a[b, 0].any()
+                    for k in range(1, K):
+                        x0, x1, y0, y1 = want[b, k]
+                        ref = np.zeros((H, W), np.float32)
+                        ref[y0:y1 + 1, x0:x1 + 1] = 1
+                        assert np.array_equal(a[b, k], ref), (i, L, npt, b, k)
+
+
+def test_long_memory_stress_size_meets_the_oracle_on_sampled_queries(oracle_mod):
+    """BASELINE configs[4] at its exact shape -- 720p (45x80 cells), 3 objects, T = 20 memory frames, regional --
+    against the ORACLE (not a second HIP kernel) on 288 sampled query cells per object: inside the query box, on
+    its edges, and masked cells outside it; through the bank (bk_main) and through the drop-in entry."""
+    from rmnet_amd import ops
+    no, T, h, w = 3, 20, 45, 80
+    rng = np.random.RandomState(420)
+    g = torch.Generator(device='cpu').manual_seed(420)
+    mk = (torch.randn(no, 128, T, h, w, generator=g) * 0.6)
+    mv = torch.randn(no, 512, T, h, w, generator=g)
+    qk = (torch.randn(no, 128, h, w, generator=g) * 0.6)
+    qv = torch.randn(no, 512, h, w, generator=g)
+    mr = np.zeros((no, T, 4), np.int32)
+    qr = np.zeros((no, 4), np.int32)
+    for o in range(no):
+        for t in range(T):
+            x0, y0 = rng.randint(0, w // 2), rng.randint(0, h // 2)
+            mr[o, t] = (x0, x0 + rng.randint(w // 3, w // 2 + 1), y0, y0 + rng.randint(h // 3, h // 2 + 1))
+        mr[o, 7] = (1, 0, 1, 0)                                      # one frame with an empty box
+        x0, y0 = rng.randint(0, w // 3), rng.randint(0, h // 3)
+        qr[o] = (x0, x0 + w // 2, y0, y0 + h // 2)
+    # sample: the four corners and edge midpoints of every query box, random cells, cells outside the boxes
+    qidx = set()
+    for o in range(no):
+        x0, x1, y0, y1 = qr[o]
+        for (yy, xx) in ((y0, x0), (y0, x1), (y1, x0), (y1, x1), ((y0 + y1) // 2, x0), (y0, (x0 + x1) // 2)):
+            qidx.add(yy * w + xx)
+    qidx.update(int(v) for v in rng.choice(h * w, size=288 - len(qidx), replace=False))
+    qidx = np.array(sorted(qidx)[:288], np.int32)
+    want = oracle_mod.regional_memory_read_sampled(mk.numpy(), mv.numpy(), qk.numpy(), mr, qr, qidx)   # [no, nq, 512]
+    d = dev()
+    bank = ops.MemoryBank(no, T, h, w, d)
+    for t in range(T):
+        bank.append(t, mk[:, :, t].contiguous().to(d), mv[:, :, t].contiguous().to(d), cu(mr[:, t]))
+    got = bank.read(T, qk.to(d), qv.to(d), cu(qr))
+    pick = lambda out: out[:, :512].reshape(no, 512, h * w)[:, :, torch.from_numpy(qidx.astype(np.int64)).to(d)].permute(0, 2, 1).cpu().numpy()
+    np.testing.assert_allclose(pick(got), want, atol=MR_ATOL, rtol=MR_RTOL)
+    assert bank.overflow_count() == 0
+    via, _ = ops.memory_read(mk.to(d), mv.to(d), qk.to(d), qv.to(d), cu(mr), cu(qr))
+    np.testing.assert_allclose(pick(via), want, atol=MR_ATOL, rtol=MR_RTOL)
+    # the q_val half is q_val * box, exactly
+    box = torch.zeros(no, 1, h, w)
+    for o in range(no):
+        box[o, 0, qr[o, 2]:qr[o, 3] + 1, qr[o, 0]:qr[o, 1] + 1] = 1
+    assert torch.equal(got[:, 512:].cpu(), qv * box)
+
+
+@pytest.mark.parametrize('K,n_obj', [(6, 5), (11, 1)])
+def test_whole_loop_480p_five_objects_and_loader_channel_count(K, n_obj, oracle_mod):
+    """480x854, two segmented frames of the device-resident loop against the CPU path (OracleRMNet): (a) 5 objects
+    (BASELINE configs[2]); (b) K = 11 mask channels with ONE object, as the reference's test loader feeds every
+    1-object video (config.py:137 N_MAX_OBJECTS = 10, utils/data_loaders.py:207-232): 9 channels stay empty."""
+    from rmnet_amd.synthetic import synthetic_clip
+    prod, ref = _nets(oracle_mod)
+    prod.fuse_epilogues()
+    H, W, N = 480, 854, 3
+    frames, masks, flows, n_objects = synthetic_clip(N, n_obj + 1, H, W, seed=K, size=1.1 if n_obj > 1 else 2.1)
+    if K > n_obj + 1:
+        pad = torch.zeros(1, N, K - n_obj - 1, H, W, dtype=masks.dtype)
+        masks = torch.cat([masks, pad], dim=2)
+    with torch.no_grad():
+        est_cpu = ref(frames, masks, flows, n_objects, 1)
+        est = prod(frames, masks, flows, n_objects, 1).cpu()
+    assert est.shape == (1, N, K, H, W)
+    assert float((est - est_cpu).abs().max()) < 1e-3
+    lab, lab_cpu = est.argmax(2).numpy(), est_cpu.argmax(2).numpy()
+    for k in range(1, n_obj + 1):
+        assert oracle_mod.iou(lab[:, 1:] == k, lab_cpu[:, 1:] == k) >= 0.999
+    if K > n_obj + 1:
+        assert float(est[:, 1:, n_obj + 1:].max()) < 1e-6          # channels of objects that do not exist
+
+
+def test_exact_fallback_with_tiny_memory_boxes_is_not_nan(oracle_mod):
+    """Round-2 advisor finding: with the transient bank's areas in its plan, the exact-fp32 fallback (taken on the
+    device when a value leaves the fp16 window) planned sum_t ceil(area_t / 32) memory tiles although it walks
+    ceil(M / 32) compacted ones; with small boxes a split then began beyond the last cell and produced NaN.
+    8 frames of 2x5 cells, one value of 2e3: the drop-in entry must match the oracle."""
+    from rmnet_amd import ops
+    rng = np.random.RandomState(77)
+    no, T, h, w = 2, 8, 9, 13
+    mk, mv, qk, qv, mr, qr = _random_case(rng, no, T, h, w, regional=True)
+    for o in range(no):
+        for t in range(T):
+            x0, y0 = rng.randint(0, w - 5), rng.randint(0, h - 2)
+            mr[o, t] = (x0, x0 + 4, y0, y0 + 1)                      # 2 x 5 cells
+        qr[o] = (1, 11, 1, 7)
+    mv[0, 3, 2, mr[0, 2, 2], mr[0, 2, 0]] = 2.0e3                    # inside a box: out of the bank's window
+    want, _ = oracle_mod.regional_memory_read(mk, mv, qk, qv, mr, qr)
+    via, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), cu(mr), cu(qr))
+    got = via.cpu().numpy()
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, want, atol=MR_ATOL, rtol=5e-5)
+
+
+def test_memory_longer_than_512_frames(oracle_mod):
+    """models/rmnet.py:416-426 grows the memory without bound; T = 600 memorised frames (5x6 grid) through the bank
+    and through the drop-in entry (default and exact fp32), against the oracle."""
+    from rmnet_amd import ops
+    rng = np.random.RandomState(600)
+    no, T, h, w = 1, 600, 5, 6
+    mk, mv, qk, qv, mr, qr = _random_case(rng, no, T, h, w, regional=True)
+    want, _ = oracle_mod.regional_memory_read(mk, mv, qk, qv, mr, qr)
+    bank = _fill_bank(ops, mk, mv, mr)
+    np.testing.assert_allclose(bank.read(T, cu(qk), cu(qv), cu(qr)).cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL)
+    for flags in (0, ops.MR_EXACT_FP32):
+        got, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), cu(mr), cu(qr), flags=flags)
+        np.testing.assert_allclose(got.cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL)

@@ -200,3 +200,64 @@ def test_region_map_boxes_match_the_reference_box_finder(oracle_mod, golden_dir)
         assert np.array_equal(bb, want), i
         assert np.array_equal(att, box_map(want, H, W)), i
     assert len(cases.REGION_BOX_SHAPES) >= 20 and n_empty >= 5 and n_k11 >= 4
+
+
+def _region_fuzz_cases(golden_dir):
+    import sys
+    sys.path.insert(0, golden_dir)
+    import cases
+    g = np.load(os.path.join(golden_dir, 'region_fuzz.npz'))
+    for i, (B, K, H, W) in enumerate(cases.REGION_FUZZ_SHAPES):
+        m = cases.region_fuzz_case(i)
+        assert float(m.astype(np.float64).sum()) == float(g['case%02d.checksum' % i])   # same inputs as the reference saw
+        yield cases, m, g['case%02d.tight' % i], g['case%02d.npts' % i], (B, K, H, W)
+
+
+def test_region_map_loosen_clamp_count_branches_vs_reference_boxes(oracle_mod, golden_dir):
+    """reg_att_map_generator.cu:55-77 (point-count fallback, the four <= / >= clamp expressions) against expectations
+    built WITHOUT rmnet_oracle.c: the reference's own box finder (utils/helpers.py:93-102, run by make_golden.py) gives
+    the tight boxes, cases.boxes_after_loosen applies the .cu's expressions, for every n_bbox_loose_pixels in
+    {0, 1, 63, 64, 65} x n_pts_threshold in {1, 9, 10, 11}; the masks put box edges at, before and after every
+    switching distance and on every border."""
+    hit_clamp = {k: 0 for k in ('x0', 'x1', 'y0', 'y1', 'fallback', 'kept')}
+    n = 0
+    for cases, m, tight, npts, (B, K, H, W) in _region_fuzz_cases(golden_dir):
+        for L in cases.REGION_FUZZ_LOOSE:
+            for npt in cases.REGION_FUZZ_NPTS:
+                want = cases.boxes_after_loosen(tight, npts, K, H, W, npt, L).reshape(B, K, 4)
+                att, bb = oracle_mod.region_map(m, 0.5, npt, L)
+                assert np.array_equal(bb, want), (n, L, npt)
+                assert np.array_equal(att, box_map(want, H, W)), (n, L, npt)
+                for r in range(B * K):                      # the fuzz really visits every branch
+                    if r % K == 0:
+                        continue
+                    if npts[r] < npt:
+                        hit_clamp['fallback'] += 1
+                        continue
+                    x0, x1, y0, y1 = tight[r]
+                    hit_clamp['x0'] += x0 <= L and x0 > 0
+                    hit_clamp['x1'] += x1 + L >= W and x1 < W - 1
+                    hit_clamp['y0'] += y0 <= L and y0 > 0
+                    hit_clamp['y1'] += y1 + L >= H and y1 < H - 1
+                    hit_clamp['kept'] += x0 > L and x1 + L < W and y0 > L and y1 + L < H
+        n += 1
+    assert n == 40 and all(v >= 20 for v in hit_clamp.values()), hit_clamp
+
+
+def test_sampled_memory_read_is_the_full_one(oracle_mod):
+    """oracle_memory_read_sampled_f32 (used for the 720p / T = 20 parity test) == the full restatement, bit for bit."""
+    rng = np.random.RandomState(3)
+    no, T, h, w = 2, 3, 7, 9
+    mk = (rng.randn(no, 128, T, h, w) * 0.6).astype(np.float32)
+    mv = rng.randn(no, 512, T, h, w).astype(np.float32)
+    qk = (rng.randn(no, 128, h, w) * 0.6).astype(np.float32)
+    qv = rng.randn(no, 512, h, w).astype(np.float32)
+    mr = np.array([[(1, 6, 0, 4), (0, 8, 0, 6), (1, 0, 1, 0)], [(2, 7, 2, 5), (0, 3, 1, 6), (4, 8, 0, 2)]], np.int32)
+    qr = np.array([(2, 7, 1, 5), (0, 4, 0, 6)], np.int32)
+    qidx = np.array([0, 5, 11, 23, 30, 40, 62], np.int32)
+    full, _ = oracle_mod.memory_read(mk, mv, qk, qv)
+    got = oracle_mod.memory_read_sampled(mk, mv, qk, qidx)
+    assert np.array_equal(got, full[:, :512].reshape(no, 512, h * w)[:, :, qidx].transpose(0, 2, 1))
+    full_r, _ = oracle_mod.regional_memory_read(mk, mv, qk, qv, mr, qr)
+    got_r = oracle_mod.regional_memory_read_sampled(mk, mv, qk, mr, qr, qidx)
+    assert np.array_equal(got_r, full_r[:, :512].reshape(no, 512, h * w)[:, :, qidx].transpose(0, 2, 1))
