@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RMNET_ABI_VERSION 1
+#define RMNET_ABI_VERSION 2   /* 2: rmnet_bank_read_f32 takes a mutable bank; rmnet_bank_area_offset */
 
 enum {
   RMNET_OK = 0,
@@ -121,7 +121,8 @@ int rmnet_memory_read_f32(const float *m_key, const float *m_val, const float *q
                           void *workspace, size_t workspace_bytes, void *stream);
 
 /* Same call, with optional HIP events recorded on `stream` around the two kernels of the fast
- * path: ev_start before mr_main, ev_mid between mr_main and mr_combine, ev_end after mr_combine
+ * path: ev_start before the read kernel, ev_mid after it, ev_end after the combine kernel of the exact-fp32
+ * path (which returns at once when the split-fp16 bank kernel did the whole read)
  * (each a hipEvent_t as void*, any may be NULL).  bench.py uses this to time the dominant kernel
  * on the stream it actually runs on; it changes nothing else. */
 int rmnet_memory_read_f32_ev(const float *m_key, const float *m_val, const float *q_key,
@@ -138,27 +139,34 @@ int rmnet_memory_read_f32_ev(const float *m_key, const float *m_val, const float
  *           (models/rmnet.py:191-205, 239-248, 416-426) plus the read itself (:361).
  * A bank is an opaque device buffer of rmnet_bank_bytes(no, Tcap, h, w) bytes holding, per object
  * and per memorised frame ("slot"), only the cells inside that frame's box, already split into
- * fp16 hi/lo planes in the MFMA fragment order (see csrc/bank.hip).  De = 128, Do = 512.
+ * fp16 hi/lo planes in the MFMA fragment order, plus the slot's per-channel value sums (see
+ * csrc/bank.hip).  De = 128, Do = 512.  THE CALLER ZERO-FILLS A NEW BANK (it carries an overflow word and
+ * the read kernel's arrival tickets, which every read leaves at zero again).
  *   rmnet_bank_append_f32: write frame `slot` from k4 [no,128,h,w] / v4 [no,512,h,w] (fp32, the
  *       KeyValue outputs, UN-masked) and its cell rectangles rects [no,4] (NULL = whole frame).
  *       A slot may be overwritten (the tentative "previous frame" slot of models/rmnet.py:416-426).
  *   rmnet_bank_read_f32: read the first T slots with q_key [no,128,h,w], q_val [no,512,h,w] and
  *       query rectangles qry_rects [no,4] (NULL = all cells) -> mem_val [no,1024,h,w], identical in
  *       meaning to rmnet_memory_read_f32 with the same rectangles.  Arithmetic: split-fp16 MFMA
- *       (hi*hi + hi*lo + lo*hi), fp32 accumulate -- fp32-class accuracy.  ev_* as in
- *       rmnet_memory_read_f32_ev (may be NULL).
+ *       (hi*hi + hi*lo + lo*hi), fp32 accumulate -- fp32-class accuracy.  ONE kernel launch per 64 objects
+ *       does the whole of MemoryReader.forward (soft-max read, merge of the partial results by the last
+ *       workgroup of each query tile, the read-out of masked query cells, the q_val half of the cat).
+ *       The bank is not const: the launch uses its ticket words -- one stream at a time may read a given bank.
+ *       ev_* as in rmnet_memory_read_f32_ev (may be NULL; ev_mid and ev_end now bracket nothing).
  * Range: K and V are stored times 2^6; elements with |x| >= 1023.5 saturate and NaN / Inf are lost.  Every
  *       16-byte group written with such an element increments the int32 overflow word that lives at byte
- *       rmnet_bank_overflow_offset() of the bank (the caller zero-fills a new bank); a caller that cannot
- *       rule such inputs out checks it (once per clip is enough) and re-runs with
- *       rmnet_memory_read_f32(..., RMNET_MR_EXACT_FP32).  Tcap <= 512.
+ *       rmnet_bank_overflow_offset() of the bank; a caller that cannot rule such inputs out checks it (once per
+ *       clip is enough) and re-runs with rmnet_memory_read_f32(..., RMNET_MR_EXACT_FP32).
+ *       rmnet_bank_area_offset(): byte offset of the int32 [no][Tcap] table of cells stored per slot (accounting).
+ *       Tcap <= 2048.
  * ------------------------------------------------------------------------------------------- */
 size_t rmnet_bank_bytes(int no, int Tcap, int h, int w);
 size_t rmnet_bank_overflow_offset(int no, int Tcap, int h, int w);
+size_t rmnet_bank_area_offset(int no, int Tcap, int h, int w);
 int rmnet_bank_append_f32(void *bank, int no, int Tcap, int h, int w, int slot, const float *k4,
                           const float *v4, const int32_t *rects, void *stream);
 size_t rmnet_bank_read_workspace_bytes(int no, int h, int w);
-int rmnet_bank_read_f32(const void *bank, int no, int Tcap, int h, int w, int T,
+int rmnet_bank_read_f32(void *bank, int no, int Tcap, int h, int w, int T,
                         const float *q_key, const float *q_val, const int32_t *qry_rects,
                         float *mem_val, void *workspace, size_t workspace_bytes, void *stream,
                         void *ev_start, void *ev_mid, void *ev_end);

@@ -43,6 +43,7 @@ SIGNATURES = {
         ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'rmnet_bank_bytes': (ctypes.c_size_t, [ctypes.c_int] * 4),
     'rmnet_bank_overflow_offset': (ctypes.c_size_t, [ctypes.c_int] * 4),
+    'rmnet_bank_area_offset': (ctypes.c_size_t, [ctypes.c_int] * 4),
     'rmnet_bank_append_f32': (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p,
         c_f32p, c_i32p, ctypes.c_void_p]),
@@ -73,7 +74,7 @@ SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 

@@ -725,6 +725,35 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
 
 constexpr int kMaxObj = kBankMaxObj;    // objects planned together in one launch (the launcher groups more)
 
+// Partial slots of one (object, query tile) pair: a strided run (the aligned column blocks) followed by a run of
+// consecutive slots (the remainder chunks that touch the pair) -- see bank_chunks() in common.h.
+struct PairSlots {
+  int a0, na, sa, b0, count, cf;
+  __device__ inline int slot(int s_) const { return s_ < na ? a0 + s_ * sa : b0 + (s_ - na); }
+};
+__device__ inline PairSlots pair_slots(int sb, int nqt, const BankChunks& bc, int qt) {
+  PairSlots r{sb + qt, bc.nfull, nqt, 0, bc.nfull, 0};
+  if (bc.R > 0) {
+    const int v0 = qt * (bc.R + kSegCost);                                   // the pair on the virtual line
+    r.cf = v0 / bc.C;
+    const int cl = (v0 + bc.R - 1) / bc.C;                                   // remainder chunks touching it
+    r.b0 = sb + nqt * bc.nfull + r.cf + qt;
+    r.count += cl - r.cf + 1;
+  }
+  return r;
+}
+
+__device__ inline float wave_sum_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+constexpr int kEarly = 9;                                       // 16-byte units of the static part whose loads are issued at kernel entry
+constexpr int kStaticRows = kDo * kMaxObj / kSplitTargetSlots + 4;   // (object, channel) rows a workgroup's share can touch
+static_assert(kSplitMax * kQT * 4 <= 2 * kPbuf, "merge weights live in the P buffers");
+static_assert(kConsumers * 16 * 65 * 4 + 2 * 4 * kQT * 4 <= 8 * kKbuf, "epilogue scratch lives in the K ring");
+
 // Launch-wide work list (stream-K with L2-friendly order).  Per object the work is the matrix
 // nqt(o) query tiles x njt(o) memory tiles.  ONE chunk length C (tiles per workgroup) is chosen for
 // the whole launch so that the chunks of all objects fill `target` CUs, whatever the box sizes.
@@ -736,13 +765,14 @@ constexpr int kMaxObj = kBankMaxObj;    // objects planned together in one launc
 //   * the remainder block of R = njt mod C tiles: its nqt * R tiles, query-tile-major, are cut into
 //     chunks of C again; such a chunk crosses query tiles and runs several SEGMENTS (all inside the
 //     same R <= C tile columns, which fit the L2).
-// (The previous integer split count per (object, query tile) left up to a quarter of the CUs idle:
-// 96 pairs -> 2 splits -> 192 workgroups.)  Every segment owns a partial slot (common.h, plan record).
+// Every segment owns a partial slot.  A segment ends with: publish the partial (write-through stores), draw a
+// ticket on the pair's counter, and -- for the last arriver -- merge the pair and write its read-out.
 __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
   __shared__ int o_njt[kMaxObj], o_m[kMaxObj], o_nqt[kMaxObj], o_cb[kMaxObj], o_sb[kMaxObj];
   __shared__ int o_rect[kMaxObj][4];
-  __shared__ int plan_n, plan_c;
+  __shared__ int plan_n, plan_c, sflag;
+  __shared__ float smean[kStaticRows];
   char* Kl_ = lds;                                 // [ring slot][plane][8 KB]
   char* Pl_ = lds + 8 * kKbuf;                     // [buf][ntile][plane][lane*16]
   float* Al = reinterpret_cast<float*>(Pl_ + 2 * kPbuf);
@@ -762,10 +792,11 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
 #if BK_YPRIO
   if (wave >= kProducers + kConsumers / 2) __builtin_amdgcn_s_setprio(BK_YPRIO);   // experiment: the younger consumer of each SIMD
 #endif
+  const int ng = a.nobj;
+  const int hw = b.hw;
 
   // ---- launch-wide plan, computed identically by every workgroup from the device-resident boxes
   //      (no host sync)
-  const int ng = a.nobj;
   const int lane0 = tid & 63;
   // Fast path (<= 12 objects, <= 64 memorised frames): wave w owns object w, lane t its frame t; the
   // areas stay in registers, so the owner wave later builds the object's tile prefix without a
@@ -777,17 +808,35 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   } else if (tid < ng) {
     o_njt[tid] = 0; o_m[tid] = 0;
   }
-  if (tid < ng) {   // query rectangle -> compacted queries -> query tiles (+1: the mean slot)
-    int q0 = 0, q1 = b.w - 1, q2 = 0, q3 = b.h - 1;
-    if (a.qry_rects) {
-      const int32_t* q = a.qry_rects + (size_t)(a.obj0 + tid) * 4;
-      q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+  int q0 = 0, q1 = b.w - 1, q2 = 0, q3 = b.h - 1;
+  if (tid < ng && a.qry_rects) {
+    const int32_t* q = a.qry_rects + (size_t)(a.obj0 + tid) * 4;
+    q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+  }
+  // ---- static part, step 1 (cat(mem, q_val), models/rmnet.py:163; M3: q_val x box, :358): this
+  //      workgroup's share of the q_val rows of the launch's objects, 16 bytes per lane.  The loads are issued NOW
+  //      (behind the plan's own first loads: the vector-memory counter retires in order), so that they fly while the
+  //      plan waits for its dependent loads.
+  const bool vec4 = (hw & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.qv) | reinterpret_cast<uintptr_t>(a.out)) & 15) == 0;
+  const int hwv = vec4 ? hw >> 2 : hw;
+  const int s_total = ng * kDo * hwv;                                  // units (16 B or 4 B) of this launch
+  const int s_per = (s_total + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int s_begin = min(s_per * (int)blockIdx.x, s_total), s_end = min(s_begin + s_per, s_total);
+  const float* __restrict__ qv0 = a.qv + (size_t)a.obj0 * kDo * hw;      // rows (og, d) of the launch, contiguous
+  f32x4 sv[kEarly];
+  if (vec4) {
+#pragma unroll
+    for (int k = 0; k < kEarly; ++k) {
+      const int idx = min(s_begin + k * kRThreads + tid, s_total - 1);   // unconditional (a load past the share is discarded):
+      sv[k] = reinterpret_cast<const f32x4*>(qv0)[idx];                   // no branch, no wait between the loads
     }
+  }
+
+  if (tid < ng) {   // query rectangle -> compacted queries -> query tiles
     const Rect r{max(q0, 0), min(q1, b.w - 1), max(q2, 0), min(q3, b.h - 1)};
     const int Mq = r.area();
     o_rect[tid][0] = r.cx0; o_rect[tid][1] = r.cx1; o_rect[tid][2] = r.cy0; o_rect[tid][3] = r.cy1;
-    int nqt = (Mq + (Mq < b.hw ? 1 : 0) + kQT - 1) / kQT;
-    o_nqt[tid] = nqt < 1 ? 1 : nqt;
+    o_nqt[tid] = (Mq + kQT - 1) / kQT;
   }
   if (fastplan) {
     const int tiles = wave_sum((my_ar + kJT - 1) / kJT), cells = wave_sum(my_ar);
@@ -799,6 +848,21 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
       const int ar = b.area[(size_t)(a.obj0 + og) * b.Tcap + t];
       atomicAdd(&o_njt[og], (ar + kJT - 1) / kJT);
       atomicAdd(&o_m[og], ar);
+    }
+  }
+  // ---- static part, step 2: the read-out of a MASKED query cell is the mean of m_val over all T*h*w cells (uniform
+  //      soft-max of all-zero logits, file header of memory_read.hip) = the slots' column sums / (T*h*w); one wave
+  //      per (object, channel) row of this workgroup's share, lanes over the frames, fixed order.
+  const int row0 = s_begin / hwv, nrows = s_end > s_begin ? (s_end - 1) / hwv - row0 + 1 : 0;
+  {
+    const float inv_cells = 1.0f / ((float)a.T * (float)hw);
+    for (int r = wave; r < nrows; r += kProducers + kConsumers) {
+      const int row = row0 + r, og = row / kDo, d = row - og * kDo;
+      const float* __restrict__ cs = b.colsum + ((size_t)(a.obj0 + og) * b.Tcap) * kDo + d;
+      float part = 0.0f;
+      for (int t = lane0; t < a.T; t += RMNET_WAVE) part += cs[(size_t)t * kDo];
+      part = wave_sum_f(part);
+      if (lane0 == 0) smean[r] = part * inv_cells;
     }
   }
   __syncthreads();
@@ -822,14 +886,84 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   __syncthreads();
   auto sld = [](const int& x) { return __builtin_amdgcn_readfirstlane(x); };   // LDS value -> SGPR
   const int nchunks = sld(plan_n), C = sld(plan_c);
-  if ((int)blockIdx.x < ng && tid == 0) {   // plan record of object blockIdx.x for the combine kernel
+  if ((int)blockIdx.x < ng && tid == 0) {   // plan record of object blockIdx.x (tools / debugging only)
     const int og = blockIdx.x;
     int32_t* pr = a.ws_plan + (size_t)(a.obj0 + og) * kPlanInts;
     const Rect r{o_rect[og][0], o_rect[og][1], o_rect[og][2], o_rect[og][3]};
     pr[0] = r.area(); pr[1] = o_nqt[og]; pr[2] = o_njt[og]; pr[3] = o_m[og];
     pr[4] = r.cx0; pr[5] = r.cx1; pr[6] = r.cy0; pr[7] = r.cy1;
-    pr[8] = a.slot0 + o_sb[og]; pr[9] = C; pr[10] = 0; pr[11] = 1;   // (mode 1 = chunked slots)
+    pr[8] = a.slot0 + o_sb[og]; pr[9] = C; pr[10] = 0; pr[11] = 1;
   }
+
+  // ---- static part, step 3: write.  Unit (row = (og, d), cells c..c+3):
+  //        out[og][kDo + d][c..] = q_val x box            (x * 0 outside the box: NaN / Inf propagate as in the reference)
+  //        out[og][d][c]         = mean[row]              for the cells OUTSIDE the query box -- and for every cell when
+  //                                                       nothing at all is memorised inside the boxes (no pair, no merge)
+  //      The cells inside the box are written by the last arriver of their (object, query tile) pair.
+  {
+    float* __restrict__ out0 = a.out + (size_t)a.obj0 * 2 * kDo * hw;
+    const float inv_w = 1.0f / (float)b.w;
+    auto put = [&](int row, int cu, f32x4 v, int nvec) {
+      const int og = row / kDo, d = row - og * kDo;
+      const int cell0 = cu * nvec;
+      const Rect rc{o_rect[og][0], o_rect[og][1], o_rect[og][2], o_rect[og][3]};
+      const bool nomem = o_njt[og] == 0;
+      const float mu = smean[row - row0];
+      int cy = (int)((float)cell0 * inv_w), cx = cell0 - cy * b.w;     // cell0 / w without an integer division
+      if (cx < 0) { cx += b.w; --cy; }                                 // (exact below 2^23; one step of slack either way)
+      if (cx >= b.w) { cx -= b.w; ++cy; }
+      f32x4 mv = {mu, mu, mu, mu};
+      bool fill[4];
+      bool all = true, none = true;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool inside = rc.contains(cy, cx);
+        v[e] = inside ? v[e] : v[e] * 0.0f;
+        fill[e] = !inside || nomem;
+        all = all && fill[e];
+        none = none && !fill[e];
+        if (++cx == b.w) { cx = 0; ++cy; }
+      }
+      float* qdst = out0 + ((size_t)og * 2 * kDo + kDo + d) * hw + cell0;
+      float* mdst = out0 + ((size_t)og * 2 * kDo + d) * hw + cell0;
+      if (nvec == 4) {
+        *reinterpret_cast<f32x4*>(qdst) = v;
+        if (all) *reinterpret_cast<f32x4*>(mdst) = mv;
+        else if (!none) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (fill[e]) mdst[e] = mu;
+        }
+      } else {
+        qdst[0] = v[0];
+        if (fill[0]) mdst[0] = mu;
+      }
+    };
+    // unit idx = s_begin + k * kRThreads + tid  <->  (row, cu), advanced without divisions
+    int row = (s_begin + tid) / hwv, cu = (s_begin + tid) - row * hwv;
+    const int step_row = kRThreads / hwv, step_cu = kRThreads - step_row * hwv;
+    auto advance = [&]() {
+      row += step_row; cu += step_cu;
+      if (cu >= hwv) { cu -= hwv; ++row; }
+    };
+    if (vec4) {
+#pragma unroll
+      for (int k = 0; k < kEarly; ++k) {
+        if (s_begin + k * kRThreads + tid < s_end) put(row, cu, sv[k], 4);
+        advance();
+      }
+      for (int idx = s_begin + kEarly * kRThreads + tid; idx < s_end; idx += kRThreads) {
+        put(row, cu, reinterpret_cast<const f32x4*>(qv0)[idx], 4);
+        advance();
+      }
+    } else {
+      for (int idx = s_begin + tid; idx < s_end; idx += kRThreads) {
+        put(row, cu, f32x4{qv0[idx], 0.f, 0.f, 0.f}, 1);
+        advance();
+      }
+    }
+  }
+
   if ((int)blockIdx.x >= nchunks) return;
   int c;
   {
@@ -848,6 +982,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   wk.qr = Rect{sld(o_rect[og][0]), sld(o_rect[og][1]), sld(o_rect[og][2]), sld(o_rect[og][3])};
   wk.Mq = wk.qr.area();
   const int slot_obj = a.slot0 + sld(o_sb[og]);
+  const float n_out = (float)(a.T * hw - sld(o_m[og]));      // masked memory cells: S = 0, V = 0 (file header)
 
   // ---- this object's tile prefix over the T memorised frames
   if (fastplan) {
@@ -878,7 +1013,10 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     if (tid == 0) tpre[0] = 0;
   }
   __syncthreads();
-  auto run_segment = [&]() {
+
+  // One segment = the tile walk (producer / consumer roles) + its epilogue.  `sself` = this segment's position in
+  // the pair's slot list.
+  auto run_segment = [&](int sself) {
     int lo = 0, hi = a.T;   // frame of the first tile
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
@@ -888,18 +1026,174 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     int ln = lane;
     asm volatile("" : "+v"(ln));   // opaque per segment: keeps hipcc from hoisting the per-lane address
                                    // arithmetic of the loops below out of the segment loop (it then spills)
+    f32x4 acc[kCDT][4];            // consumers: O of (64 channels x 64 queries)
+    float m_seg = 0.0f, l_seg = 0.0f;   // producers: running reference (log2 domain) and sum of query 16 * wave + l15
     if (producer)
-      producer_loop(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, ln, t_entry);
+      producer_loop(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, ln, t_entry, m_seg, l_seg);
     else
-      consumer_loop(a, wk, Kl_, Pl_, Al, tpre, wave, ln, t_entry);
+      consumer_loop(a, wk, Kl_, Pl_, Al, tpre, wave, ln, t_entry, acc);
+
+    // ================= segment epilogue (all 12 waves; every barrier below is reached by all of them) =================
+    const int l15 = ln & 15, g = ln >> 4;
+    const PairSlots ps = pair_slots(slot_obj, nqt, bc, wk.qt);
+    const int nsp = ps.count;
+    constexpr size_t kSlotF = (size_t)kDo * kQT;          // floats per partial slot
+    // epilogue scratch: merge weights in the P buffers (16 KB), the rest in the (now idle) K ring
+    float* Wt = reinterpret_cast<float*>(Pl_);            // [slot of the pair][query]: 2^(m_s - m_tot)
+    float* Tw = reinterpret_cast<float*>(Kl_);            // [consumer wave][16 channels][65]: transposes
+    float* red = Tw + kConsumers * 16 * 65;               // [4][64] partial maxima
+    float* red2 = red + 4 * kQT;                          // [4][64] partial sums
+    float* Msh = Al;                                      // own (m, l) of the 64 queries
+    float* Lsh = Al + kQT;
+    if (producer && g == 0) { Msh[wave * 16 + l15] = m_seg; Lsh[wave * 16 + l15] = l_seg; }
+    if (nsp > 1 && !(BK_ABLATE & 8)) {
+      // ---- publish: write-through (sc1) stores, drained by every storing wave, THEN the ticket
+      //      (cdna_hip_programming.md section 6 Guideline 16, recipe R1 in its counter form)
+      if (!producer) {
+        float* base = a.ws_o + (size_t)wk.slot * kSlotF;
+        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(base));
+        const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(base) >> 32));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<float*>(((uintptr_t)bhi << 32) | blo), 0, (int)(kSlotF * 4), 0x00020000);
+        const int dt0 = kCDT * (wave - kProducers);
+#pragma unroll
+        for (int dt = 0; dt < kCDT; ++dt)
+#pragma unroll
+          for (int it = 0; it < 4; ++it)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[dt][it]), rs,
+                                                   (int)(partial_frag_offset(dt0 + dt, it, ln) * 4), 0, 16 /* sc1 */);
+      } else if (g == 0) {
+        float* wm = a.ws_ml + (size_t)wk.slot * 2 * kQT;
+        __hip_atomic_store(wm + wave * 16 + l15, m_seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(wm + kQT + wave * 16 + l15, l_seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                                              // E1: every wave's stores have landed
+      if (tid == 0) {
+        int* cnt = b.cnt + (size_t)wk.o * bank_nqt_max(hw) + wk.qt;
+        const int t = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == nsp - 1) {                    // last arriver: see the others' stores; leave the counter clean for the next read
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        sflag = t;
+      }
+      __syncthreads();                                                              // E2
+      if (sld(sflag) != nsp - 1) return;       // somebody else merges this pair
+    } else {
+      __syncthreads();                                                              // (Msh / Lsh visible)
+    }
+    // ---- merge (last arriver; or the only segment of the pair).  Producers: the pair's weights.
+    //      thread (sl = wave, qi = lane): query qi, slots sl, sl + 4, ...
+    constexpr int kMl = 4;
+    float m_r[kMl], l_r[kMl];
+    if (producer) {
+      const int qi = ln, sl = wave;
+      float mloc = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < kMl; ++j) {
+        const int sj = sl + 4 * j;
+        m_r[j] = -INFINITY; l_r[j] = 0.0f;
+        if (sj == sself) { m_r[j] = Msh[qi]; l_r[j] = Lsh[qi]; }
+        else if (sj < nsp) {
+          const float* e = a.ws_ml + (size_t)ps.slot(sj) * 2 * kQT;
+          m_r[j] = e[qi]; l_r[j] = e[kQT + qi];
+        }
+        mloc = fmaxf(mloc, m_r[j]);
+      }
+      for (int sj = sl + 4 * kMl; sj < nsp; sj += 4)
+        mloc = fmaxf(mloc, sj == sself ? Msh[qi] : a.ws_ml[(size_t)ps.slot(sj) * 2 * kQT + qi]);
+      red[sl * kQT + qi] = mloc;
+    }
+    __syncthreads();                                                                // E3
+    if (producer) {
+      const int qi = ln, sl = wave;
+      float mtot = fmaxf(fmaxf(red[qi], red[kQT + qi]), fmaxf(red[2 * kQT + qi], red[3 * kQT + qi]));
+      if (n_out > 0.0f) mtot = fmaxf(mtot, 0.0f);          // the masked memory cells have S = 0
+      float lloc = 0.0f;
+#pragma unroll
+      for (int j = 0; j < kMl; ++j) {
+        const int sj = sl + 4 * j;
+        const float wgt = __builtin_amdgcn_exp2f(m_r[j] - mtot);     // (-inf for a slot that does not exist: 0)
+        if (sj < nsp) Wt[sj * kQT + qi] = wgt;
+        lloc += l_r[j] * wgt;
+      }
+      for (int sj = sl + 4 * kMl; sj < nsp; sj += 4) {
+        const float* e = a.ws_ml + (size_t)ps.slot(sj) * 2 * kQT;
+        const float ms = sj == sself ? Msh[qi] : e[qi], ls = sj == sself ? Lsh[qi] : e[kQT + qi];
+        const float wgt = __builtin_amdgcn_exp2f(ms - mtot);
+        Wt[sj * kQT + qi] = wgt;
+        lloc += ls * wgt;
+      }
+      // (the closed-form term N_out * 2^(-m_tot) of the masked memory cells rides in group 0's partial sum)
+      red2[sl * kQT + qi] = lloc + (sl == 0 && n_out > 0.0f ? n_out * __builtin_amdgcn_exp2f(-mtot) : 0.0f);
+    }
+    __syncthreads();                                                                // E4
+    if (!producer) {
+      // ---- consumers: O = (own x w_self + sum_s partial_s x w_s) / l_tot for this wave's 64 channels x 64 queries
+      const int dt0 = kCDT * (wave - kProducers);
+      float wq[4], iq[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int q = it * 16 + l15;
+        wq[it] = Wt[sself * kQT + q];
+        iq[it] = kBankValueUnscale / (red2[q] + red2[kQT + q] + red2[2 * kQT + q] + red2[3 * kQT + q]);
+      }
+#pragma unroll
+      for (int dt = 0; dt < kCDT; ++dt)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) acc[dt][it] *= wq[it];
+      for (int s_ = 0; s_ < nsp; ++s_) {
+        if (s_ == sself) continue;
+        const float* src = a.ws_o + (size_t)ps.slot(s_) * kSlotF;
+        f32x4 v[kCDT][4];
+#pragma unroll
+        for (int dt = 0; dt < kCDT; ++dt)
+#pragma unroll
+          for (int it = 0; it < 4; ++it)
+            v[dt][it] = *reinterpret_cast<const f32x4*>(src + partial_frag_offset(dt0 + dt, it, ln));
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const float ws_ = Wt[s_ * kQT + it * 16 + l15];
+#pragma unroll
+          for (int dt = 0; dt < kCDT; ++dt) acc[dt][it] += ws_ * v[dt][it];
+        }
+      }
+      // ---- transpose 16 channels x 64 queries at a time through this wave's LDS patch and scatter to the cells:
+      //      a store instruction covers 64 consecutive compacted queries of one channel row
+      float* T = Tw + (wave - kProducers) * 16 * 65;
+      const int nq = wk.qt * kQT + ln;
+      const bool qvalid = nq < wk.Mq;
+      int cell = 0;
+      if (qvalid) {
+        const int rw = wk.qr.width(), ry = nq / rw;
+        cell = (wk.qr.cy0 + ry) * b.w + wk.qr.cx0 + (nq - ry * rw);
+      }
+      float* __restrict__ outo = a.out + (size_t)wk.o * 2 * kDo * hw + cell;
+#pragma unroll
+      for (int dt = 0; dt < kCDT; ++dt) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) T[(4 * g + r) * 65 + it * 16 + l15] = acc[dt][it][r] * iq[it];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ch = 0; ch < 16; ++ch) {
+          const float x = T[ch * 65 + ln];
+          if (qvalid) outo[(size_t)(16 * (dt0 + dt) + ch) * hw] = x;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
   };
+
   if (cl < nqt * bc.nfull) {          // aligned chunk: (column block, query tile), one segment
     const int blk = cl / nqt;
     wk.qt = cl - blk * nqt;
     wk.jt0 = blk * C;
     wk.ntl = C;
     wk.slot = slot_obj + cl;
-    run_segment();
+    run_segment(blk);
 #if BK_CLK
     if (tid == 0) {   // experiments: shader cycles vs constant-rate (100 MHz) clock of this workgroup
       long long* cb = reinterpret_cast<long long*>(a.ws_plan + (size_t)(a.obj0 + a.nobj) * kPlanInts + 16) + 2 * blockIdx.x;
@@ -920,9 +1214,9 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     wk.jt0 = bc.nfull * C + j0;
     wk.ntl = j1 - j0;
     wk.slot = slot_obj + nqt * bc.nfull + cr + qt;
-    if (!first) __syncthreads();      // the previous segment's LDS (K ring, P, alpha) is free
+    if (!first) __syncthreads();      // the previous segment's LDS (K ring, P, alpha, epilogue scratch) is free
     first = false;
-    run_segment();
+    run_segment(bc.nfull + cr - (qt * span) / C);
   }
 }
 
@@ -944,6 +1238,8 @@ int launch_bank_stage(void* bank, int no, int Tcap, int h, int w, int slot0, int
   const BankView b = bank_view(bank, no, Tcap, h, w);
   hipLaunchKernelGGL(bk_append, dim3(b.hwp / kJT, no * nf, 1 + kDo / kDe), dim3(kThreads), 0, st, b, slot0, nf,
                      k4, v4, k_cs, k_os, v_cs, v_os, rects);
+  if (int e = check_launch()) return e;
+  hipLaunchKernelGGL(bk_colsum, dim3(no * nf), dim3(kDo), 0, st, b, slot0, nf);
   return check_launch();
 }
 
@@ -951,8 +1247,9 @@ size_t bank_overflow_offset(int no, int Tcap, int h, int w) { return bank_bytes(
 
 int launch_bank_main(const BankReadArgs& m, hipStream_t st) {
   BArgs a;
-  a.b = bank_view(const_cast<void*>(m.bank), m.no, m.Tcap, m.h, m.w);
+  a.b = bank_view(m.bank, m.no, m.Tcap, m.h, m.w);
   a.qk = m.qk; a.qv = m.qv; a.qry_rects = m.qry_rects;
+  a.out = m.out;
   a.ws_o = m.ws_o; a.ws_ml = m.ws_ml; a.ws_plan = m.ws_plan;
   a.T = m.T;
   a.gate = m.gate;

@@ -82,6 +82,11 @@ size_t rmnet_bank_bytes(int no, int Tcap, int h, int w) {
   return bank_bytes(no, Tcap, h, w);
 }
 
+size_t rmnet_bank_area_offset(int no, int Tcap, int h, int w) {
+  if (no <= 0 || Tcap <= 0 || h <= 0 || w <= 0) return 0;
+  return bank_area_offset(no, Tcap, h, w);
+}
+
 size_t rmnet_bank_overflow_offset(int no, int Tcap, int h, int w) {
   if (no <= 0 || Tcap <= 0 || h <= 0 || w <= 0) return 0;
   return bank_overflow_offset(no, Tcap, h, w);
@@ -97,7 +102,7 @@ size_t rmnet_bank_read_workspace_bytes(int no, int h, int w) {
   return bank_read_ws_bytes(no, h, w);
 }
 
-int rmnet_bank_read_f32(const void* bank, int no, int Tcap, int h, int w, int T, const float* q_key,
+int rmnet_bank_read_f32(void* bank, int no, int Tcap, int h, int w, int T, const float* q_key,
                         const float* q_val, const int32_t* qry_rects, float* mem_val,
                         void* workspace, size_t workspace_bytes, void* stream, void* ev_start,
                         void* ev_mid, void* ev_end) {

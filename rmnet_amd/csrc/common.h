@@ -121,6 +121,7 @@ struct BankView {
 BankView bank_view(void* base, int no, int Tcap, int h, int w);
 size_t bank_bytes(int no, int Tcap, int h, int w);
 size_t bank_area_offset(int no, int Tcap, int h, int w);
+size_t bank_ctl_bytes(int no, int h, int w);      // overflow word + arrival tickets (zero in a new bank)
 constexpr float kBankValueUnscale = 1.0f / 64.0f;   // values are stored times 2^6 (bank.hip)
 
 // Split heuristic shared by the read kernels and the combine kernel (must agree exactly).

@@ -72,10 +72,8 @@ struct KArgs {
   long long mk_cs, mk_os, mv_cs, mv_os;
   int slots;                 // workgroup slots per object (grid.x of mr_main)
   float sqrt_de;
-  const int32_t* bank_area;  // non-null: memory side comes from a bank (areas [no][bank_tcap])
-  int bank_tcap;
-  const int32_t* gate;       // non-null: the overflow word of a transient bank (drop-in entry): mr_main runs
-                             // only when it is set, and the combine then reads mr_main's (natural-log) partials
+  const int32_t* gate;       // non-null: the overflow word of a transient bank (drop-in entry): mr_main and
+                             // mr_combine run only when it is set (bk_main has then returned at once)
 };
 
 struct Plan {
@@ -130,18 +128,7 @@ __device__ inline Plan make_plan(const KArgs& a, int o, int* prefix) {
     p.Mq = a.hw;
     p.qr = Rect{0, a.w - 1, 0, a.h - 1};
   }
-  if (a.bank_area) {   // memory side of a split-fp16 bank: cells and 32-cell tiles per frame
-    int m = 0, tiles = 0;
-    for (int t = 0; t < a.T; ++t) {
-      const int ar = a.bank_area[(size_t)o * a.bank_tcap + t];
-      m += ar;
-      tiles += (ar + kJT - 1) / kJT;
-    }
-    p.M = m;
-    p.njt = tiles;
-  } else {
-    p.njt = (p.M + kJT - 1) / kJT;
-  }
+  p.njt = (p.M + kJT - 1) / kJT;
   const BankPlan bp = bank_plan(p.Mq, a.hw, p.njt, a.no, a.slots);
   p.nqt = bp.nqt;
   p.nsplit = bp.nsplit;
@@ -354,7 +341,7 @@ __global__ __launch_bounds__(kThreads, 1) void mr_main(const KArgs a) {
 // Measured at 480p/T=5: 1 object 20.0 vs 22.1 us, 8 objects 39.2 vs 33.1 us.
 inline int comb_channels(int no) { return no <= 2 ? 16 : 32; }
 
-// Merge the per-split partials (fragment-ordered blocks, common.h).
+// Merge the per-split partials of mr_main (fragment-ordered blocks, common.h).
 // grid = (nqt_max + cell tiles, kDo / kCombCh, no).  The plan comes from the 32-byte record the read
 // kernel left behind (one load instead of re-deriving it).
 //   blocks [0, nqt_max)   : one compacted query tile x 64 channels each (exit beyond the live tiles):
@@ -368,8 +355,8 @@ inline int comb_channels(int no) { return no <= 2 ? 16 : 32; }
 //        output line has one writer; with them goes the q_val half of the cat (models/rmnet.py:163).
 //   blocks [nqt_max, ...) : one tile of 64 grid cells each, for the rows ABOVE and BELOW the query
 //        box only (mean-slot vector, q_val * 0).  Skipped when nothing is masked.
-// The bank kernel keeps its running reference in the log2 domain (2^x soft-max), mr_main in the
-// natural one; a.bank_area tells which.
+// Only mr_main's partials come here (natural-log running reference); the split-fp16 bank kernel merges its
+// own (bank.hip) and this kernel returns at once when the drop-in entry's gate says the bank path ran.
 // blocks [copy_x0, gridDim.x) (only when copy_x0 > 0): the q_val half of the cat as a streaming copy --
 //        mem_val[o][Do + d][:] = q_val[o][d][:] * box, 16 bytes per lane along the channel rows (needs
 //        h * w % 4 == 0, as on RMNet's grids).  The query-tile blocks used to carry it in 256-byte runs
@@ -384,36 +371,22 @@ __global__ __launch_bounds__(kThreads, kCombCh == 16 ? 6 : 5) void mr_combine(co
   __shared__ float Tt[kCombCh][kQT + 1];
   __shared__ float Tm[kCombCh];
   const int tid = threadIdx.x, o = blockIdx.z;
+  if (a.gate && __builtin_amdgcn_readfirstlane(*a.gate) == 0) return;   // the split-fp16 bank path did the whole read
   Plan pl;
-  int p8, p9, mode;
+  int p8;
   {
     const int32_t* pr = a.ws_plan + (size_t)o * kPlanInts;
     pl.Mq = pr[0]; pl.nqt = pr[1]; pl.nsplit = pr[2]; pl.M = pr[3];
     pl.qr = Rect{pr[4], pr[5], pr[6], pr[7]};
     pl.njt = 0;
     p8 = __builtin_amdgcn_readfirstlane(pr[8]);
-    p9 = __builtin_amdgcn_readfirstlane(pr[9]);
-    mode = __builtin_amdgcn_readfirstlane(pr[11]);
   }
-  // Partial slots of one (object, query tile) pair (plan record, common.h): a strided run (mr_main's
-  // splits / bk_main's aligned column blocks) followed by a run of consecutive slots (bk_main's
-  // remainder chunks).
+  // Partial slots of one (object, query tile) pair (plan record, common.h): slot first + s * nqt + qt.
   struct PairSlots {
-    int a0, na, sa, b0, count;
-    __device__ inline int slot(int s_) const { return s_ < na ? a0 + s_ * sa : b0 + (s_ - na); }
+    int a0, sa, count;
+    __device__ inline int slot(int s_) const { return a0 + s_ * sa; }
   };
-  auto pair_slots = [&](int qt_) -> PairSlots {
-    if (mode == 0) return PairSlots{p8 + qt_, pl.nsplit, pl.nqt, 0, pl.nsplit};   // first + s * nqt + qt
-    const BankChunks bc = bank_chunks(pl.nqt, pl.nsplit, p9);                  // (mode 1 stores njt in [2], C in [9])
-    PairSlots r{p8 + qt_, bc.nfull, pl.nqt, 0, bc.nfull};
-    if (bc.R > 0) {
-      const int v0 = qt_ * (bc.R + kSegCost);                                     // the pair on the virtual line
-      const int cf = v0 / bc.C, cl = (v0 + bc.R - 1) / bc.C;                      // remainder chunks touching it
-      r.b0 = p8 + pl.nqt * bc.nfull + cf + qt_;
-      r.count += cl - cf + 1;
-    }
-    return r;
-  };
+  auto pair_slots = [&](int qt_) -> PairSlots { return PairSlots{p8 + qt_, pl.nqt, pl.nsplit}; };
   if (copy_x0 > 0 && (int)blockIdx.x >= copy_x0) {
     const int hw4 = a.hw >> 2, n4 = kCombCh * hw4, d0c = blockIdx.y * kCombCh;
     const Rect rc = REGIONAL ? pl.qr : Rect{0, a.w - 1, 0, a.h - 1};
@@ -434,8 +407,7 @@ __global__ __launch_bounds__(kThreads, kCombCh == 16 ? 6 : 5) void mr_combine(co
     return;
   }
   const bool qv_here = copy_x0 == 0;                      // the merge / fill blocks below write the q_val half themselves
-  const bool log2d = a.bank_area != nullptr && !(a.gate && __builtin_amdgcn_readfirstlane(*a.gate) != 0);
-  const float vun = log2d ? kBankValueUnscale : 1.0f;   // the bank stores values times 2^6
+  const float vun = 1.0f;
   const int qi = tid & 63, sl = tid >> 6;
   const float n_out = (float)(a.T * a.hw - pl.M);
   const float* __restrict__ ml = a.ws_ml;
@@ -454,10 +426,10 @@ __global__ __launch_bounds__(kThreads, kCombCh == 16 ? 6 : 5) void mr_combine(co
     if (pl.Mq > 0 && y0 >= pl.qr.cy0 && y1 <= pl.qr.cy1) return;
   }
   const int d0 = blockIdx.y * kCombCh;
-  const PairSlots ps = fill ? PairSlots{0, 0, 1, 0, 0} : pair_slots(qt);
+  const PairSlots ps = fill ? PairSlots{0, 1, 0} : pair_slots(qt);
   const int nsp = ps.count;                             // partials of this query tile
   constexpr size_t kSlotF = (size_t)kDo * kQT;          // floats per partial slot
-  auto ex = [&](float x) { return log2d ? exp2f(x) : expf(x); };
+  auto ex = [&](float x) { return expf(x); };
 
   // First batch of this tile's partial fragments: requested NOW, before the weights are known, so
   // that their latency overlaps the (m, l) loads and the three barriers of the weight phase.
@@ -488,7 +460,7 @@ __global__ __launch_bounds__(kThreads, kCombCh == 16 ? 6 : 5) void mr_combine(co
   __shared__ float red2[4][kQT];
   __shared__ float tp[kTmParts][kCombCh];
   const int qtm = pl.Mq >> 6, mq = pl.Mq & 63;
-  const PairSlots pm = masked ? pair_slots(qtm) : PairSlots{0, 0, 1, 0, 0};   // the mean slot's query tile
+  const PairSlots pm = masked ? pair_slots(qtm) : PairSlots{0, 1, 0};   // the mean slot's query tile
   float m_r[kMl], l_r[kMl];
   if (!fill) {
 #pragma unroll
@@ -837,18 +809,19 @@ int launch_memory_read(const MemReadArgs& m, hipStream_t st) {
     a.mk_cs = mk_cs; a.mk_os = mk_os; a.mv_cs = mv_cs; a.mv_os = mv_os;
     a.slots = slots_for(m.no, (int)hw);
     a.sqrt_de = sqrt_de;
-    a.bank_area = nullptr; a.bank_tcap = 0; a.gate = nullptr;
+    a.gate = nullptr;
     a.ws_o = static_cast<float*>(m.ws);
     a.ws_ml = reinterpret_cast<float*>(static_cast<char*>(m.ws) + align256(nslots * kDo * kQT * 4));
     a.ws_plan = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.ws_ml) + align256(nslots * 2 * kQT * 4));
     char* bank = reinterpret_cast<char*>(a.ws_plan) + align256((size_t)m.no * kPlanInts * 4);
     if (via_bank) {
       const BankView b = bank_view(bank, m.no, m.T, m.h, m.w);
-      if (hipMemsetAsync(b.ovf, 0, sizeof(int32_t), st) != hipSuccess) return RMNET_E_LAUNCH;
+      // control block of the transient bank: the overflow word and the pairs' arrival tickets (the workspace is arbitrary memory)
+      if (hipMemsetAsync(b.ovf, 0, bank_ctl_bytes(m.no, m.h, m.w), st) != hipSuccess) return RMNET_E_LAUNCH;
       if (int e = launch_bank_stage(bank, m.no, m.T, m.h, m.w, 0, m.T, m.mk, m.mv, mk_cs, mk_os, mv_cs, mv_os,
                                     m.mem_rects, st))
         return e;
-      a.bank_area = b.area; a.bank_tcap = m.T; a.gate = b.ovf;
+      a.gate = b.ovf;
     }
     const int nqt_max = (int)((hw + 1 + kQT - 1) / kQT);
     dim3 g1(a.slots, m.no);
@@ -863,19 +836,12 @@ int launch_memory_read(const MemReadArgs& m, hipStream_t st) {
       r.ws = nullptr; r.ws_bytes = 0; r.gate = 1;
       if (int e = launch_bank_main(r, st)) return e;
     }
-    {
-      // mr_main walks the COMPACTED cell list of the fp32 tensors (ceil(M / 32) tiles); the transient bank's
-      // per-frame tile count (sum_t ceil(area_t / 32), what bk_main walks) must not leak into its plan: with
-      // small boxes a split would start beyond the last cell (-inf - -inf = NaN).  Only the combine needs
-      // bank_area (log2-domain partials of bk_main).
-      KArgs am = a;
-      am.bank_area = nullptr;
-      am.bank_tcap = 0;
-      if (regional)
-        hipLaunchKernelGGL(mr_main<true>, g1, dim3(kThreads), 0, st, am);
-      else
-        hipLaunchKernelGGL(mr_main<false>, g1, dim3(kThreads), 0, st, am);
-    }
+    // (mr_main plans its own ceil(M / 32) compacted tiles from the rectangles: the transient bank's per-frame tile
+    //  count must never enter its plan -- round 2 leaked it there and small boxes produced NaN)
+    if (regional)
+      hipLaunchKernelGGL(mr_main<true>, g1, dim3(kThreads), 0, st, a);
+    else
+      hipLaunchKernelGGL(mr_main<false>, g1, dim3(kThreads), 0, st, a);
     if (int e = check_launch()) return e;
     if (m.ev_mid && hipEventRecord(m.ev_mid, st) != hipSuccess) return RMNET_E_LAUNCH;
     if (regional)
@@ -932,27 +898,12 @@ int launch_bank_read(BankReadArgs& m, hipStream_t st) {
   m.ws_o = static_cast<float*>(m.ws);
   m.ws_ml = reinterpret_cast<float*>(static_cast<char*>(m.ws) + align256(tslots * kDo * kQT * 4));
   m.ws_plan = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(m.ws_ml) + align256(tslots * 2 * kQT * 4));
+  // ONE kernel: bk_main writes the q_val half and the masked cells while it waits for its plan, reads, and the last
+  // arriver of every (object, query tile) pair merges the pair's partials and writes the read-out (bank.hip).
+  // ev_mid is kept for the callers that bracket "main" and "combine" separately: the second bracket is now empty.
   if (m.ev_start && hipEventRecord(m.ev_start, st) != hipSuccess) return RMNET_E_LAUNCH;
   if (int e = launch_bank_main(m, st)) return e;
   if (m.ev_mid && hipEventRecord(m.ev_mid, st) != hipSuccess) return RMNET_E_LAUNCH;
-  const BankView b = bank_view(const_cast<void*>(m.bank), m.no, m.Tcap, m.h, m.w);
-  KArgs a;
-  a.mk = a.mv = nullptr; a.qk = m.qk; a.qv = m.qv; a.out = m.out;
-  a.mem_rects = nullptr; a.qry_rects = m.qry_rects;
-  a.no = m.no; a.T = m.T; a.h = m.h; a.w = m.w; a.hw = hw;
-  a.mk_cs = a.mk_os = a.mv_cs = a.mv_os = 0;
-  a.slots = m.slots; a.sqrt_de = 0.0f;
-  a.bank_area = b.area; a.bank_tcap = m.Tcap; a.gate = nullptr;
-  a.ws_o = m.ws_o; a.ws_ml = m.ws_ml; a.ws_plan = m.ws_plan;
-  const int nqt_max = (hw + 1 + kQT - 1) / kQT;
-  const bool qreg = m.qry_rects != nullptr;
-  const int cch = comb_channels(m.no);
-  dim3 g2((unsigned)(nqt_max + (qreg ? (hw + kQT - 1) / kQT : 0)), kDo / cch, m.no);
-  if (qreg)
-    launch_combine(true, cch, g2, st, a, nqt_max);
-  else
-    launch_combine(false, cch, g2, st, a, nqt_max);
-  if (int e = check_launch()) return e;
   if (m.ev_end && hipEventRecord(m.ev_end, st) != hipSuccess) return RMNET_E_LAUNCH;
   return RMNET_OK;
 }

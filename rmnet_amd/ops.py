@@ -199,10 +199,8 @@ class MemoryBank:
         _lib.check(rc, 'rmnet_bank_append_f32')
 
     def areas(self):
-        """[no, capacity] int32 view of the per-slot cell counts kept at the tail of the blob (debug /
-        accounting only; mirrors bank_view() in csrc/bank.hip)."""
-        hwp = (self.h * self.w + 31) // 32 * 32
-        off = 2 * self.no * self.capacity * hwp * 128 * 2 + 2 * self.no * self.capacity * 512 * hwp * 2
+        """[no, capacity] int32 view of the per-slot cell counts kept in the blob (debug / accounting only)."""
+        off = _lib.load().rmnet_bank_area_offset(self.no, self.capacity, self.h, self.w)
         return self.blob[off:off + self.no * self.capacity * 4].view(torch.int32).view(self.no, self.capacity)
 
     def overflow_count(self):
