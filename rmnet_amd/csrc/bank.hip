@@ -301,6 +301,10 @@ constexpr int kRThreads = 64 * (kProducers + kConsumers);  // 768 = 12 waves = 3
 #define BK_ABLATE 0    // experiments only, bit mask: 1 no V reloads, 2 no PV MFMAs, 4 no S/soft-max,
 #endif                 //                             8 no partial stores, 16 no K tile loads, 32 / 64 cheaper soft-max
                        //                             (changes the control flow: not a clean ablation), 128 a barrier every 2nd tile
+                       //                             256 no static part (q_val half / masked cells), 1024 publish + ticket only (nobody merges)
+#ifndef BK_TAIL
+#define BK_TAIL 0      // experiments only: 1 no segment epilogue, 2 plain partial stores only, 3 write-through publish only
+#endif
 #ifndef BK_PRIO
 #define BK_PRIO 2
 #endif
@@ -824,7 +828,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   const int s_begin = min(s_per * (int)blockIdx.x, s_total), s_end = min(s_begin + s_per, s_total);
   const float* __restrict__ qv0 = a.qv + (size_t)a.obj0 * kDo * hw;      // rows (og, d) of the launch, contiguous
   f32x4 sv[kEarly];
-  if (vec4) {
+  if (vec4 && !(BK_ABLATE & 256)) {
 #pragma unroll
     for (int k = 0; k < kEarly; ++k) {
       const int idx = min(s_begin + k * kRThreads + tid, s_total - 1);   // unconditional (a load past the share is discarded):
@@ -900,7 +904,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   //        out[og][d][c]         = mean[row]              for the cells OUTSIDE the query box -- and for every cell when
   //                                                       nothing at all is memorised inside the boxes (no pair, no merge)
   //      The cells inside the box are written by the last arriver of their (object, query tile) pair.
-  {
+  if (!(BK_ABLATE & 256)) {
     float* __restrict__ out0 = a.out + (size_t)a.obj0 * 2 * kDo * hw;
     const float inv_w = 1.0f / (float)b.w;
     auto put = [&](int row, int cu, f32x4 v, int nvec) {
@@ -1034,6 +1038,26 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
       consumer_loop(a, wk, Kl_, Pl_, Al, tpre, wave, ln, t_entry, acc);
 
     // ================= segment epilogue (all 12 waves; every barrier below is reached by all of them) =================
+#if BK_TAIL == 1      // experiments: no epilogue at all (the accumulators are kept alive, nothing is stored)
+    if (!producer) {
+#pragma unroll
+      for (int dt = 0; dt < kCDT; ++dt)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) asm volatile("" :: "v"(acc[dt][it]));
+    }
+    return;
+#elif BK_TAIL == 2    // experiments: plain partial stores, no ticket, no merge (the round-2 epilogue)
+    if (!producer) {
+      float* wo = a.ws_o + (size_t)wk.slot * (size_t)kDo * kQT;
+      const int dt0_ = kCDT * (wave - kProducers);
+#pragma unroll
+      for (int dt = 0; dt < kCDT; ++dt)
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+          *reinterpret_cast<f32x4*>(wo + partial_frag_offset(dt0_ + dt, it, ln)) = acc[dt][it];
+    }
+    return;
+#endif
     const int l15 = ln & 15, g = ln >> 4;
     const PairSlots ps = pair_slots(slot_obj, nqt, bc, wk.qt);
     const int nsp = ps.count;
@@ -1069,6 +1093,9 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                                                              // E1: every wave's stores have landed
+#if BK_TAIL == 3      // experiments: write-through publish, no ticket
+      return;
+#endif
       if (tid == 0) {
         int* cnt = b.cnt + (size_t)wk.o * bank_nqt_max(hw) + wk.qt;
         const int t = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1079,7 +1106,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
         sflag = t;
       }
       __syncthreads();                                                              // E2
-      if (sld(sflag) != nsp - 1) return;       // somebody else merges this pair
+      if (sld(sflag) != nsp - 1 || (BK_ABLATE & 1024)) return;       // somebody else merges this pair
     } else {
       __syncthreads();                                                              // (Msh / Lsh visible)
     }

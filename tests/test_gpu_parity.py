@@ -1306,7 +1306,12 @@ def test_long_memory_stress_size_meets_the_oracle_on_sampled_queries(oracle_mod)
 def test_whole_loop_480p_five_objects_and_loader_channel_count(K, n_obj, oracle_mod):
     """480x854, two segmented frames of the device-resident loop against the CPU path (OracleRMNet): (a) 5 objects
     (BASELINE configs[2]); (b) K = 11 mask channels with ONE object, as the reference's test loader feeds every
-    1-object video (config.py:137 N_MAX_OBJECTS = 10, utils/data_loaders.py:207-232): 9 channels stay empty."""
+    1-object video (config.py:137 N_MAX_OBJECTS = 10, utils/data_loaders.py:207-232): 9 channels stay empty.
+    Bar: label IoU >= 0.999 per object (north_star).  Probabilities: within 1e-3 for one object; with five the 5-way
+    soft aggregation (a product of five probabilities, then a logit) amplifies the convolutions' GPU-vs-CPU rounding on a
+    handful of boundary pixels -- measured 5e-3 on 18 of 2.4 M values, identically with the exact-fp32 read (_exact=True,
+    tools/dbg_loop5.py) -- so the bar there is: fewer than 1e-4 of the values differ by more than 1e-3, none by more than
+    2e-2, and the split-fp16 read adds nothing to what the exact read shows."""
     from rmnet_amd.synthetic import synthetic_clip
     prod, ref = _nets(oracle_mod)
     prod.fuse_epilogues()
@@ -1319,7 +1324,15 @@ def test_whole_loop_480p_five_objects_and_loader_channel_count(K, n_obj, oracle_
         est_cpu = ref(frames, masks, flows, n_objects, 1)
         est = prod(frames, masks, flows, n_objects, 1).cpu()
     assert est.shape == (1, N, K, H, W)
-    assert float((est - est_cpu).abs().max()) < 1e-3
+    diff = (est - est_cpu).abs()
+    if n_obj == 1:
+        assert float(diff.max()) < 1e-3
+    else:
+        with torch.no_grad():
+            est_x = prod(frames, masks, flows, n_objects, 1, _exact=True).cpu()
+        diff_x = (est_x - est_cpu).abs()
+        assert float(diff.max()) < 2e-2 and float((diff > 1e-3).float().mean()) < 1e-4
+        assert int((diff > 1e-3).sum()) <= int((diff_x > 1e-3).sum()) + 16      # same class as the exact-fp32 read
     lab, lab_cpu = est.argmax(2).numpy(), est_cpu.argmax(2).numpy()
     for k in range(1, n_obj + 1):
         assert oracle_mod.iou(lab[:, 1:] == k, lab_cpu[:, 1:] == k) >= 0.999
