@@ -134,7 +134,7 @@ BankView bank_view(void* base, int no, int Tcap, int h, int w) {
   return b;
 }
 
-size_t bank_ctl_bytes(int no, int h, int w) { return 256 + align256((size_t)no * bank_nqt_max(h * w) * 4); }
+size_t bank_ctl_bytes(int no, int h, int w) { return 256 + align256((size_t)no * bank_nqt_max(h * w) * 2 * 4); }
 
 size_t bank_bytes(int no, int Tcap, int h, int w) {
   const size_t hwp = ((size_t)h * w + kJT - 1) / kJT * kJT;
@@ -303,7 +303,7 @@ constexpr int kRThreads = 64 * (kProducers + kConsumers);  // 768 = 12 waves = 3
                        //                             (changes the control flow: not a clean ablation), 128 a barrier every 2nd tile
                        //                             256 no static part (q_val half / masked cells), 1024 publish + ticket only (nobody merges)
 #ifndef BK_TAIL
-#define BK_TAIL 0      // experiments only: 1 no segment epilogue, 2 plain partial stores only, 3 write-through publish only
+#define BK_TAIL 0      // experiments only: 1 no segment epilogue (accumulators kept alive, nothing stored)
 #endif
 #ifndef BK_PRIO
 #define BK_PRIO 2
@@ -753,14 +753,30 @@ __device__ inline float wave_sum_f(float v) {
   return v;
 }
 
-constexpr int kEarly = 9;                                       // 16-byte units of the static part whose loads are issued at kernel entry
-constexpr int kStaticRows = kDo * kMaxObj / kSplitTargetSlots + 4;   // (object, channel) rows a workgroup's share can touch
+// ---- static part of the read: the outputs that do not depend on the soft-max --------------------------------------
+//   out[o][kDo + d][cell] = q_val[o][d][cell] x box(o)        (cat(mem, q_val), models/rmnet.py:163; the box of :358)
+//   out[o][d][cell]       = mean_j m_val[o][d][j]            for the query cells OUTSIDE the box: all their logits are 0,
+//                           the soft-max is uniform over all T*h*w memory cells (file header of memory_read.hip);
+//                           = sum of the slots' column sums (bk_append / bk_colsum) / (T*h*w).  Also written for the
+//                           cells inside the box when nothing is memorised inside any memory box (no pair, no merge).
+// It is ~2.6x the q_val bytes of HBM traffic and no arithmetic: measured as a prologue of every workgroup it cost
+// 11-14 us (a bandwidth-bound burst in front of the tile loops); as a WORK QUEUE (one ticket word in the bank) it is
+// drained by a few workgroups that get no chunk (the plan sets them aside, scaled to the launch) while the others
+// compute, and by every workgroup that has finished its segments -- among them the early arrivers of a pair, while
+// the pair's last arriver merges.
+constexpr int kStaticUnits = 9;                                 // 16-byte units per thread and queue item (at most), all in flight at once
+constexpr int kStaticRows = 128;                                // (object, channel) rows per queue item, at most
+#ifndef BK_STATIC_BPUS
+#define BK_STATIC_BPUS 50.0e3f
+#endif
+constexpr float kStaticBytesPerUs = BK_STATIC_BPUS;             // what one streaming workgroup moves (sizing of the set-aside)
+constexpr float kTileUs = 1.75f, kLaunchUs = 12.0f;             // tile step / fixed part of a compute workgroup (same estimate)
 static_assert(kSplitMax * kQT * 4 <= 2 * kPbuf, "merge weights live in the P buffers");
 static_assert(kConsumers * 16 * 65 * 4 + 2 * 4 * kQT * 4 <= 8 * kKbuf, "epilogue scratch lives in the K ring");
 
 // Launch-wide work list (stream-K with L2-friendly order).  Per object the work is the matrix
 // nqt(o) query tiles x njt(o) memory tiles.  ONE chunk length C (tiles per workgroup) is chosen for
-// the whole launch so that the chunks of all objects fill `target` CUs, whatever the box sizes.
+// the whole launch so that the chunks of all objects fill the compute workgroups, whatever the box sizes.
 // Object o is cut into
 //   * nfull = njt / C column blocks of exactly C tiles: nqt * nfull chunks of ONE segment each,
 //     (block, query tile) in block-major order -- the nqt workgroups of a block walk the same K/V
@@ -769,8 +785,10 @@ static_assert(kConsumers * 16 * 65 * 4 + 2 * 4 * kQT * 4 <= 8 * kKbuf, "epilogue
 //   * the remainder block of R = njt mod C tiles: its nqt * R tiles, query-tile-major, are cut into
 //     chunks of C again; such a chunk crosses query tiles and runs several SEGMENTS (all inside the
 //     same R <= C tile columns, which fit the L2).
-// Every segment owns a partial slot.  A segment ends with: publish the partial (write-through stores), draw a
-// ticket on the pair's counter, and -- for the last arriver -- merge the pair and write its read-out.
+// Every segment owns a partial slot.  A segment ends with a ticket on its pair's arrival counter: the early arrivers
+// publish their partial (O, m, l) with write-through stores and count themselves done; the LAST arriver keeps its
+// partial in registers, waits until the others are done (they are past their loops: the wait cannot deadlock,
+// whatever is resident), merges the pair and writes its read-out.
 __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
   __shared__ int o_njt[kMaxObj], o_m[kMaxObj], o_nqt[kMaxObj], o_cb[kMaxObj], o_sb[kMaxObj];
@@ -798,6 +816,8 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
 #endif
   const int ng = a.nobj;
   const int hw = b.hw;
+  int* q_head = b.ovf + 16;                        // control block of the bank: static work queue (next item) ...
+  int* q_exit = b.ovf + 32;                        // ... workgroups that have left the kernel (the last one zeroes both)
 
   // ---- launch-wide plan, computed identically by every workgroup from the device-resident boxes
   //      (no host sync)
@@ -812,31 +832,12 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   } else if (tid < ng) {
     o_njt[tid] = 0; o_m[tid] = 0;
   }
-  int q0 = 0, q1 = b.w - 1, q2 = 0, q3 = b.h - 1;
-  if (tid < ng && a.qry_rects) {
-    const int32_t* q = a.qry_rects + (size_t)(a.obj0 + tid) * 4;
-    q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
-  }
-  // ---- static part, step 1 (cat(mem, q_val), models/rmnet.py:163; M3: q_val x box, :358): this
-  //      workgroup's share of the q_val rows of the launch's objects, 16 bytes per lane.  The loads are issued NOW
-  //      (behind the plan's own first loads: the vector-memory counter retires in order), so that they fly while the
-  //      plan waits for its dependent loads.
-  const bool vec4 = (hw & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.qv) | reinterpret_cast<uintptr_t>(a.out)) & 15) == 0;
-  const int hwv = vec4 ? hw >> 2 : hw;
-  const int s_total = ng * kDo * hwv;                                  // units (16 B or 4 B) of this launch
-  const int s_per = (s_total + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int s_begin = min(s_per * (int)blockIdx.x, s_total), s_end = min(s_begin + s_per, s_total);
-  const float* __restrict__ qv0 = a.qv + (size_t)a.obj0 * kDo * hw;      // rows (og, d) of the launch, contiguous
-  f32x4 sv[kEarly];
-  if (vec4 && !(BK_ABLATE & 256)) {
-#pragma unroll
-    for (int k = 0; k < kEarly; ++k) {
-      const int idx = min(s_begin + k * kRThreads + tid, s_total - 1);   // unconditional (a load past the share is discarded):
-      sv[k] = reinterpret_cast<const f32x4*>(qv0)[idx];                   // no branch, no wait between the loads
-    }
-  }
-
   if (tid < ng) {   // query rectangle -> compacted queries -> query tiles
+    int q0 = 0, q1 = b.w - 1, q2 = 0, q3 = b.h - 1;
+    if (a.qry_rects) {
+      const int32_t* q = a.qry_rects + (size_t)(a.obj0 + tid) * 4;
+      q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+    }
     const Rect r{max(q0, 0), min(q1, b.w - 1), max(q2, 0), min(q3, b.h - 1)};
     const int Mq = r.area();
     o_rect[tid][0] = r.cx0; o_rect[tid][1] = r.cx1; o_rect[tid][2] = r.cy0; o_rect[tid][3] = r.cy1;
@@ -854,28 +855,23 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
       atomicAdd(&o_m[og], ar);
     }
   }
-  // ---- static part, step 2: the read-out of a MASKED query cell is the mean of m_val over all T*h*w cells (uniform
-  //      soft-max of all-zero logits, file header of memory_read.hip) = the slots' column sums / (T*h*w); one wave
-  //      per (object, channel) row of this workgroup's share, lanes over the frames, fixed order.
-  const int row0 = s_begin / hwv, nrows = s_end > s_begin ? (s_end - 1) / hwv - row0 + 1 : 0;
-  {
-    const float inv_cells = 1.0f / ((float)a.T * (float)hw);
-    for (int r = wave; r < nrows; r += kProducers + kConsumers) {
-      const int row = row0 + r, og = row / kDo, d = row - og * kDo;
-      const float* __restrict__ cs = b.colsum + ((size_t)(a.obj0 + og) * b.Tcap) * kDo + d;
-      float part = 0.0f;
-      for (int t = lane0; t < a.T; t += RMNET_WAVE) part += cs[(size_t)t * kDo];
-      part = wave_sum_f(part);
-      if (lane0 == 0) smean[r] = part * inv_cells;
-    }
-  }
   __syncthreads();
   if (tid < RMNET_WAVE) {   // one wave, lane = object
     const int nqt = tid < ng ? o_nqt[tid] : 0, njt = tid < ng ? o_njt[tid] : 0;
     const int W = wave_sum(nqt * njt), njt_max = wave_max(njt);
+    // workgroups set aside for the static part: what it takes to stream it in about the time the others compute
+    // (the finishers drain whatever is left, so a wrong guess costs little either way)
+    int target = a.target;
+    if (!(BK_ABLATE & 256)) {
+      const float static_bytes = (float)ng * (float)hw * (float)kDo * 4.0f * 2.5f;
+      const float compute_us = kLaunchUs + kTileUs * (float)W / (float)a.target;
+      int aside = (int)(static_bytes / (compute_us * kStaticBytesPerUs) + 0.5f);
+      aside = min(aside, a.target / 4);
+      target = a.target - aside;
+    }
     // smallest chunk length whose chunks fit `target` workgroups (sum_o nch(o) shrinks as C grows)
-    int C0 = max((W + a.target - 1) / a.target, bank_chunk_min(njt_max));
-    for (int it = 0; it < 1024 && wave_sum(bank_chunks(nqt, njt, C0).nch) > a.target; ++it) C0 += 1 + (C0 >> 5);
+    int C0 = max((W + target - 1) / target, bank_chunk_min(njt_max));
+    for (int it = 0; it < 1024 && wave_sum(bank_chunks(nqt, njt, C0).nch) > target; ++it) C0 += 1 + (C0 >> 5);
     const BankChunks bc0 = bank_chunks(nqt, njt, C0);
     int nch = bc0.nch, nsl = bc0.nch + (bc0.R > 0 ? nqt : 0);   // chunks; slots (a remainder chunk can add one per query tile)
     const int my_ch = nch, my_sl = nsl;
@@ -899,76 +895,8 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     pr[8] = a.slot0 + o_sb[og]; pr[9] = C; pr[10] = 0; pr[11] = 1;
   }
 
-  // ---- static part, step 3: write.  Unit (row = (og, d), cells c..c+3):
-  //        out[og][kDo + d][c..] = q_val x box            (x * 0 outside the box: NaN / Inf propagate as in the reference)
-  //        out[og][d][c]         = mean[row]              for the cells OUTSIDE the query box -- and for every cell when
-  //                                                       nothing at all is memorised inside the boxes (no pair, no merge)
-  //      The cells inside the box are written by the last arriver of their (object, query tile) pair.
-  if (!(BK_ABLATE & 256)) {
-    float* __restrict__ out0 = a.out + (size_t)a.obj0 * 2 * kDo * hw;
-    const float inv_w = 1.0f / (float)b.w;
-    auto put = [&](int row, int cu, f32x4 v, int nvec) {
-      const int og = row / kDo, d = row - og * kDo;
-      const int cell0 = cu * nvec;
-      const Rect rc{o_rect[og][0], o_rect[og][1], o_rect[og][2], o_rect[og][3]};
-      const bool nomem = o_njt[og] == 0;
-      const float mu = smean[row - row0];
-      int cy = (int)((float)cell0 * inv_w), cx = cell0 - cy * b.w;     // cell0 / w without an integer division
-      if (cx < 0) { cx += b.w; --cy; }                                 // (exact below 2^23; one step of slack either way)
-      if (cx >= b.w) { cx -= b.w; ++cy; }
-      f32x4 mv = {mu, mu, mu, mu};
-      bool fill[4];
-      bool all = true, none = true;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const bool inside = rc.contains(cy, cx);
-        v[e] = inside ? v[e] : v[e] * 0.0f;
-        fill[e] = !inside || nomem;
-        all = all && fill[e];
-        none = none && !fill[e];
-        if (++cx == b.w) { cx = 0; ++cy; }
-      }
-      float* qdst = out0 + ((size_t)og * 2 * kDo + kDo + d) * hw + cell0;
-      float* mdst = out0 + ((size_t)og * 2 * kDo + d) * hw + cell0;
-      if (nvec == 4) {
-        *reinterpret_cast<f32x4*>(qdst) = v;
-        if (all) *reinterpret_cast<f32x4*>(mdst) = mv;
-        else if (!none) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (fill[e]) mdst[e] = mu;
-        }
-      } else {
-        qdst[0] = v[0];
-        if (fill[0]) mdst[0] = mu;
-      }
-    };
-    // unit idx = s_begin + k * kRThreads + tid  <->  (row, cu), advanced without divisions
-    int row = (s_begin + tid) / hwv, cu = (s_begin + tid) - row * hwv;
-    const int step_row = kRThreads / hwv, step_cu = kRThreads - step_row * hwv;
-    auto advance = [&]() {
-      row += step_row; cu += step_cu;
-      if (cu >= hwv) { cu -= hwv; ++row; }
-    };
-    if (vec4) {
-#pragma unroll
-      for (int k = 0; k < kEarly; ++k) {
-        if (s_begin + k * kRThreads + tid < s_end) put(row, cu, sv[k], 4);
-        advance();
-      }
-      for (int idx = s_begin + kEarly * kRThreads + tid; idx < s_end; idx += kRThreads) {
-        put(row, cu, reinterpret_cast<const f32x4*>(qv0)[idx], 4);
-        advance();
-      }
-    } else {
-      for (int idx = s_begin + tid; idx < s_end; idx += kRThreads) {
-        put(row, cu, f32x4{qv0[idx], 0.f, 0.f, 0.f}, 1);
-        advance();
-      }
-    }
-  }
-
-  if ((int)blockIdx.x >= nchunks) return;
+  // =========================================== compute: this workgroup's chunk ===========================================
+  auto compute = [&]() {
   int c;
   {
     const int q8 = nchunks >> 3, r8 = nchunks & 7, x = blockIdx.x & 7;   // XCD-contiguous logical ids
@@ -1046,17 +974,6 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
         for (int it = 0; it < 4; ++it) asm volatile("" :: "v"(acc[dt][it]));
     }
     return;
-#elif BK_TAIL == 2    // experiments: plain partial stores, no ticket, no merge (the round-2 epilogue)
-    if (!producer) {
-      float* wo = a.ws_o + (size_t)wk.slot * (size_t)kDo * kQT;
-      const int dt0_ = kCDT * (wave - kProducers);
-#pragma unroll
-      for (int dt = 0; dt < kCDT; ++dt)
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-          *reinterpret_cast<f32x4*>(wo + partial_frag_offset(dt0_ + dt, it, ln)) = acc[dt][it];
-    }
-    return;
 #endif
     const int l15 = ln & 15, g = ln >> 4;
     const PairSlots ps = pair_slots(slot_obj, nqt, bc, wk.qt);
@@ -1069,51 +986,81 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     float* red2 = red + 4 * kQT;                          // [4][64] partial sums
     float* Msh = Al;                                      // own (m, l) of the 64 queries
     float* Lsh = Al + kQT;
+    const int dt0 = kCDT * (wave - kProducers);           // (consumers) first channel tile of this wave
+    auto slot_rsrc = [&](int slot) {                      // buffer descriptor of a partial slot (wave-uniform base)
+      float* base = a.ws_o + (size_t)slot * kSlotF;
+      const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(base));
+      const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(base) >> 32));
+      return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((uintptr_t)bhi << 32) | blo), 0,
+                                               (int)(kSlotF * 4), 0x00020000);
+    };
     if (producer && g == 0) { Msh[wave * 16 + l15] = m_seg; Lsh[wave * 16 + l15] = l_seg; }
     if (nsp > 1 && !(BK_ABLATE & 8)) {
-      // ---- publish: write-through (sc1) stores, drained by every storing wave, THEN the ticket
-      //      (cdna_hip_programming.md section 6 Guideline 16, recipe R1 in its counter form)
-      if (!producer) {
-        float* base = a.ws_o + (size_t)wk.slot * kSlotF;
-        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(base));
-        const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(base) >> 32));
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            reinterpret_cast<float*>(((uintptr_t)bhi << 32) | blo), 0, (int)(kSlotF * 4), 0x00020000);
-        const int dt0 = kCDT * (wave - kProducers);
+      int* arrive = b.cnt + 2 * ((size_t)wk.o * bank_nqt_max(hw) + wk.qt);
+      int* done = arrive + 1;
+      if (tid == 0) sflag = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();                                                              // E1: the ticket (and Msh / Lsh)
+      const int ticket = sld(sflag);
+      if (ticket != nsp - 1) {
+        // ---- early arriver: publish with write-through (sc1) stores, drained by every storing wave, THEN count done
+        //      (cdna_hip_programming.md section 6 Guideline 16, recipe R1 in its counter form)
+        if (!producer) {
+          const __amdgpu_buffer_rsrc_t rs = slot_rsrc(wk.slot);
 #pragma unroll
-        for (int dt = 0; dt < kCDT; ++dt)
+          for (int dt = 0; dt < kCDT; ++dt)
 #pragma unroll
-          for (int it = 0; it < 4; ++it)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[dt][it]), rs,
-                                                   (int)(partial_frag_offset(dt0 + dt, it, ln) * 4), 0, 16 /* sc1 */);
-      } else if (g == 0) {
-        float* wm = a.ws_ml + (size_t)wk.slot * 2 * kQT;
-        __hip_atomic_store(wm + wave * 16 + l15, m_seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(wm + kQT + wave * 16 + l15, l_seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();                                                              // E1: every wave's stores have landed
-#if BK_TAIL == 3      // experiments: write-through publish, no ticket
-      return;
-#endif
-      if (tid == 0) {
-        int* cnt = b.cnt + (size_t)wk.o * bank_nqt_max(hw) + wk.qt;
-        const int t = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == nsp - 1) {                    // last arriver: see the others' stores; leave the counter clean for the next read
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int it = 0; it < 4; ++it)
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[dt][it]), rs,
+                                                     (int)(partial_frag_offset(dt0 + dt, it, ln) * 4), 0, 16 /* sc1 */);
+        } else if (g == 0) {
+          float* wm = a.ws_ml + (size_t)wk.slot * 2 * kQT;
+          __hip_atomic_store(wm + wave * 16 + l15, m_seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(wm + kQT + wave * 16 + l15, l_seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        sflag = t;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                                            // every wave's stores have landed
+        if (tid == 0) __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;                                 // the pair's last arriver merges
       }
-      __syncthreads();                                                              // E2
-      if (sld(sflag) != nsp - 1 || (BK_ABLATE & 1024)) return;       // somebody else merges this pair
+      // ---- last arriver: its own partial stays in registers.  Wait for the others' publications: they all hold a
+      //      ticket, i.e. they have left their tile loops and only store -- the wait ends whatever else is (not) resident.
+      if (tid == 0) {
+        int polls = 0;
+        while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nsp - 1) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++polls > (1 << 22)) { atomicAdd(b.ovf, 1 << 20); break; }   // (cannot happen; never hang the GPU: report as overflow)
+        }
+        __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean counters for the next read
+        __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (BK_ABLATE & 1024) return;
+      __syncthreads();                                                              // E2: all partials of the pair are in memory
     } else {
       __syncthreads();                                                              // (Msh / Lsh visible)
     }
-    // ---- merge (last arriver; or the only segment of the pair).  Producers: the pair's weights.
-    //      thread (sl = wave, qi = lane): query qi, slots sl, sl + 4, ...
+    // ---- merge (last arriver; or the only segment of the pair).  The others' partials were stored write-through and are
+    //      read with sc1 loads (L2-coherent at agent scope: no acquire fence, no L1 invalidate needed).
+    //      Consumers request the first foreign slot's fragments NOW, before the weights exist.
+    int s_first = sself == 0 ? 1 : 0;                      // first foreign slot (if any)
+    constexpr int kEarlyDt = kCDT / 2;                     // channel tiles of the early batch (registers: the whole slot spills)
+    u32x4 v0[kEarlyDt][4];
+    if (!producer && nsp > 1) {
+      const __amdgpu_buffer_rsrc_t rs = slot_rsrc(ps.slot(s_first));
+#pragma unroll
+      for (int dt = 0; dt < kEarlyDt; ++dt)
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+          v0[dt][it] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(partial_frag_offset(dt0 + dt, it, ln) * 4), 0, 16 /* sc1 */);
+    }
+    //      Producers: the pair's weights.  thread (sl = wave, qi = lane): query qi, slots sl, sl + 4, ...
     constexpr int kMl = 4;
     float m_r[kMl], l_r[kMl];
+    auto ml_load = [&](int sj, int qi, float& m_, float& l_) {
+      if (sj == sself) { m_ = Msh[qi]; l_ = Lsh[qi]; return; }
+      const float* e = a.ws_ml + (size_t)ps.slot(sj) * 2 * kQT;
+      m_ = __hip_atomic_load(e + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      l_ = __hip_atomic_load(e + kQT + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     if (producer) {
       const int qi = ln, sl = wave;
       float mloc = -INFINITY;
@@ -1121,15 +1068,14 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
       for (int j = 0; j < kMl; ++j) {
         const int sj = sl + 4 * j;
         m_r[j] = -INFINITY; l_r[j] = 0.0f;
-        if (sj == sself) { m_r[j] = Msh[qi]; l_r[j] = Lsh[qi]; }
-        else if (sj < nsp) {
-          const float* e = a.ws_ml + (size_t)ps.slot(sj) * 2 * kQT;
-          m_r[j] = e[qi]; l_r[j] = e[kQT + qi];
-        }
+        if (sj < nsp) ml_load(sj, qi, m_r[j], l_r[j]);
         mloc = fmaxf(mloc, m_r[j]);
       }
-      for (int sj = sl + 4 * kMl; sj < nsp; sj += 4)
-        mloc = fmaxf(mloc, sj == sself ? Msh[qi] : a.ws_ml[(size_t)ps.slot(sj) * 2 * kQT + qi]);
+      for (int sj = sl + 4 * kMl; sj < nsp; sj += 4) {
+        float ms, ls;
+        ml_load(sj, qi, ms, ls);
+        mloc = fmaxf(mloc, ms);
+      }
       red[sl * kQT + qi] = mloc;
     }
     __syncthreads();                                                                // E3
@@ -1146,8 +1092,8 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
         lloc += l_r[j] * wgt;
       }
       for (int sj = sl + 4 * kMl; sj < nsp; sj += 4) {
-        const float* e = a.ws_ml + (size_t)ps.slot(sj) * 2 * kQT;
-        const float ms = sj == sself ? Msh[qi] : e[qi], ls = sj == sself ? Lsh[qi] : e[kQT + qi];
+        float ms, ls;
+        ml_load(sj, qi, ms, ls);
         const float wgt = __builtin_amdgcn_exp2f(ms - mtot);
         Wt[sj * kQT + qi] = wgt;
         lloc += ls * wgt;
@@ -1158,7 +1104,6 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     __syncthreads();                                                                // E4
     if (!producer) {
       // ---- consumers: O = (own x w_self + sum_s partial_s x w_s) / l_tot for this wave's 64 channels x 64 queries
-      const int dt0 = kCDT * (wave - kProducers);
       float wq[4], iq[4];
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
@@ -1170,20 +1115,37 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
       for (int dt = 0; dt < kCDT; ++dt)
 #pragma unroll
         for (int it = 0; it < 4; ++it) acc[dt][it] *= wq[it];
-      for (int s_ = 0; s_ < nsp; ++s_) {
+      if (nsp > 1) {
+        const __amdgpu_buffer_rsrc_t rs = slot_rsrc(ps.slot(s_first));
+        u32x4 v1[kCDT - kEarlyDt][4];                      // the rest of the first foreign slot
+#pragma unroll
+        for (int dt = kEarlyDt; dt < kCDT; ++dt)
+#pragma unroll
+          for (int it = 0; it < 4; ++it)
+            v1[dt - kEarlyDt][it] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(partial_frag_offset(dt0 + dt, it, ln) * 4), 0, 16 /* sc1 */);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const float ws_ = Wt[s_first * kQT + it * 16 + l15];
+#pragma unroll
+          for (int dt = 0; dt < kEarlyDt; ++dt) acc[dt][it] += ws_ * __builtin_bit_cast(f32x4, v0[dt][it]);
+#pragma unroll
+          for (int dt = kEarlyDt; dt < kCDT; ++dt) acc[dt][it] += ws_ * __builtin_bit_cast(f32x4, v1[dt - kEarlyDt][it]);
+        }
+      }
+      for (int s_ = s_first + 1; s_ < nsp; ++s_) {
         if (s_ == sself) continue;
-        const float* src = a.ws_o + (size_t)ps.slot(s_) * kSlotF;
-        f32x4 v[kCDT][4];
+        const __amdgpu_buffer_rsrc_t rs = slot_rsrc(ps.slot(s_));
+        u32x4 v[kCDT][4];
 #pragma unroll
         for (int dt = 0; dt < kCDT; ++dt)
 #pragma unroll
           for (int it = 0; it < 4; ++it)
-            v[dt][it] = *reinterpret_cast<const f32x4*>(src + partial_frag_offset(dt0 + dt, it, ln));
+            v[dt][it] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(partial_frag_offset(dt0 + dt, it, ln) * 4), 0, 16 /* sc1 */);
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const float ws_ = Wt[s_ * kQT + it * 16 + l15];
 #pragma unroll
-          for (int dt = 0; dt < kCDT; ++dt) acc[dt][it] += ws_ * v[dt][it];
+          for (int dt = 0; dt < kCDT; ++dt) acc[dt][it] += ws_ * __builtin_bit_cast(f32x4, v[dt][it]);
         }
       }
       // ---- transpose 16 channels x 64 queries at a time through this wave's LDS patch and scatter to the cells:
@@ -1221,13 +1183,6 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     wk.ntl = C;
     wk.slot = slot_obj + cl;
     run_segment(blk);
-#if BK_CLK
-    if (tid == 0) {   // experiments: shader cycles vs constant-rate (100 MHz) clock of this workgroup
-      long long* cb = reinterpret_cast<long long*>(a.ws_plan + (size_t)(a.obj0 + a.nobj) * kPlanInts + 16) + 2 * blockIdx.x;
-      cb[0] = (long long)__builtin_readcyclecounter() - t_entry;
-      cb[1] = (long long)__builtin_amdgcn_s_memrealtime() - t_real;
-    }
-#endif
     return;
   }
   // remainder chunk: units [u0, u1) of the virtual line over the last R tile columns (common.h)
@@ -1244,6 +1199,165 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     if (!first) __syncthreads();      // the previous segment's LDS (K ring, P, alpha, epilogue scratch) is free
     first = false;
     run_segment(bc.nfull + cr - (qt * span) / C);
+  }
+  };   // compute()
+  if ((int)blockIdx.x < nchunks) {
+    compute();
+#if BK_CLK
+    if (tid == 0) {   // experiments: shader cycles vs constant-rate (100 MHz) clock of this workgroup's compute part
+      long long* cb = reinterpret_cast<long long*>(a.ws_plan + (size_t)(a.obj0 + a.nobj) * kPlanInts + 16) + 2 * blockIdx.x;
+      cb[0] = (long long)__builtin_readcyclecounter() - t_entry;
+      cb[1] = (long long)__builtin_amdgcn_s_memrealtime() - t_real;
+    }
+#endif
+  }
+
+  // =========================================== static part: drain the queue ===========================================
+  // A queue item = `rpc` consecutive (object, channel) rows of ONE object (rpc is a power of two <= 128, so items never
+  // straddle objects).  The box test is per CELL, the same for every channel row: it is evaluated once per object into
+  // an LDS byte per unit (bits 0-3: cell inside the query box, bits 4-7: cell gets the mean), so the per-unit work is a
+  // load, four selects and one or two stores -- a stream, not arithmetic.
+  if (!(BK_ABLATE & 256)) {
+    const bool vec4 = (hw & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.qv) | reinterpret_cast<uintptr_t>(a.out)) & 15) == 0;
+    const int hwv = vec4 ? hw >> 2 : hw, nvec = vec4 ? 4 : 1;
+    constexpr int kB = kStaticUnits;                   // units per thread and item = loads in flight per buffer
+    int rpc = 1;
+    while (rpc < kStaticRows && rpc * 2 * hwv <= kB * kRThreads) rpc *= 2;
+    const int nrow_total = ng * kDo, nitems = nrow_total / rpc;              // (kDo is a multiple of rpc)
+    const int nunits = rpc * hwv;                                            // <= kB * kRThreads unless one row alone is longer
+    const float* __restrict__ qv0 = a.qv + (size_t)a.obj0 * kDo * hw;      // rows (og, d) of the launch, contiguous
+    float* __restrict__ out0 = a.out + (size_t)a.obj0 * 2 * kDo * hw;
+    const float inv_cells = 1.0f / ((float)a.T * (float)hw);
+    const int step_row = kRThreads / hwv, step_cu = kRThreads - step_row * hwv;
+    unsigned char* umask = reinterpret_cast<unsigned char*>(Kl_);          // [2][hwv] (the K ring is idle here)
+    float* smean2 = reinterpret_cast<float*>(Kl_ + 2 * ((hwv + 15) & ~15));  // [2][kStaticRows]
+
+    auto issue = [&](int it, f32x4 (&dst)[kB]) {       // the first kB units per thread of item `it` (unconditional loads)
+      const float* __restrict__ src = qv0 + (size_t)it * rpc * hw;
+#pragma unroll
+      for (int k = 0; k < kB; ++k) {
+        const int u = min(k * kRThreads + tid, nunits - 1);
+        dst[k] = vec4 ? reinterpret_cast<const f32x4*>(src)[u] : f32x4{src[u], 0.f, 0.f, 0.f};
+      }
+    };
+    auto means = [&](int it, int buf) {                // column sums of the item's rows -> smean2[buf]: one wave per row, lanes
+      const int r0 = it * rpc, og_ = r0 / kDo;         // over the frames, fixed order; two rows per step and wave
+      const float* __restrict__ cs0 = b.colsum + ((size_t)(a.obj0 + og_) * b.Tcap) * kDo + (r0 - og_ * kDo);
+      for (int ra = wave; ra < rpc; ra += 2 * (kProducers + kConsumers)) {
+        const int rb = ra + kProducers + kConsumers;
+        float pa = 0.0f, pb = 0.0f;
+        for (int t = lane0; t < a.T; t += RMNET_WAVE) {
+          pa += cs0[(size_t)t * kDo + ra];
+          if (rb < rpc) pb += cs0[(size_t)t * kDo + rb];
+        }
+        pa = wave_sum_f(pa);
+        pb = wave_sum_f(pb);
+        if (lane0 == 0) {
+          smean2[buf * kStaticRows + ra] = pa * inv_cells;
+          if (rb < rpc) smean2[buf * kStaticRows + rb] = pb * inv_cells;
+        }
+      }
+    };
+    auto mask_build = [&](int og, int buf) {
+      const Rect rc{o_rect[og][0], o_rect[og][1], o_rect[og][2], o_rect[og][3]};
+      const bool nomem = o_njt[og] == 0;
+      for (int cu = tid; cu < hwv; cu += kRThreads) {
+        int cell = cu * nvec, cy = cell / b.w, cx = cell - cy * b.w;
+        unsigned m = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool inside = e < nvec && rc.contains(cy, cx);
+          m |= (inside ? 1u : 0u) << e;
+          m |= ((!inside || nomem) && e < nvec ? 1u : 0u) << (4 + e);
+          if (++cx == b.w) { cx = 0; ++cy; }
+        }
+        umask[buf * hwv + cu] = (unsigned char)m;
+      }
+    };
+    auto write_unit = [&](int it, int row, int cu, f32x4 x, int sbuf, int mbuf) {
+      const int r0 = it * rpc, og = r0 / kDo;
+      float* __restrict__ qdst = out0 + ((size_t)og * kDo + kDo + r0) * hw;   // out[og][kDo + d]: row index og * 2 kDo + kDo + d
+      float* __restrict__ mdst = out0 + ((size_t)og * kDo + r0) * hw;         // out[og][d]
+      const unsigned m = umask[mbuf * hwv + cu];
+      const float mu = smean2[sbuf * kStaticRows + row];
+      const int off = row * hw + cu * nvec;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = (m >> e & 1u) ? x[e] : x[e] * 0.0f;   // x * 0: NaN / Inf propagate as in the reference
+      if (vec4) {
+        *reinterpret_cast<f32x4*>(qdst + off) = x;
+        if ((m >> 4) == 15u) *reinterpret_cast<f32x4*>(mdst + off) = f32x4{mu, mu, mu, mu};
+        else if (m >> 4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (m >> (4 + e) & 1u) mdst[off + e] = mu;
+        }
+      } else {
+        qdst[off] = x[0];
+        if (m >> 4 & 1u) mdst[off] = mu;
+      }
+    };
+
+    __syncthreads();                                   // (the compute part's LDS traffic is over; sflag is free)
+    if (tid == 0) sflag = __hip_atomic_fetch_add(q_head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    int item = sld(sflag);
+    int sbuf = 0, mbuf = 0, og = 0;
+    f32x4 v[kB];                                       // ONE set of load registers: an item's loads are issued right after the
+    int t_next = 0;                                    // previous item's stores (a spill here would put a vmcnt(0) drain --
+                                                       // scratch is vector memory -- behind every unit: measured 40 us per item)
+    if (item < nitems) {
+      og = item * rpc / kDo;
+      issue(item, v);
+      if (tid == 0) t_next = __hip_atomic_fetch_add(q_head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      mask_build(og, mbuf);
+      means(item, sbuf);
+    }
+    __syncthreads();                                   // (nobody reads the first sflag any more)
+    if (tid == 0) sflag = t_next;
+    __syncthreads();
+    int next = sld(sflag);
+    while (item < nitems) {
+      // ---- write item `item` (its loads were issued one step ago)
+      int row = tid / hwv, cu = tid - row * hwv;       // this thread's units: u = tid, tid + kRThreads, ...; no division per unit
+#pragma unroll
+      for (int k = 0; k < kB; ++k) {
+        if (k * kRThreads + tid < nunits) write_unit(item, row, cu, v[k], sbuf, mbuf);
+        row += step_row; cu += step_cu;
+        if (cu >= hwv) { cu -= hwv; ++row; }
+      }
+      for (int u = kB * kRThreads + tid; u < nunits; u += kRThreads) {     // (only when one row alone exceeds an item: huge grids)
+        const float* __restrict__ src = qv0 + (size_t)item * rpc * hw;
+        write_unit(item, row, cu, vec4 ? reinterpret_cast<const f32x4*>(src)[u] : f32x4{src[u], 0.f, 0.f, 0.f}, sbuf, mbuf);
+        row += step_row; cu += step_cu;
+        if (cu >= hwv) { cu -= hwv; ++row; }
+      }
+      // ---- request the next item: loads, column sums, masks of a new object, the ticket after it
+      const bool more = next < nitems;
+      const int og_next = more ? next * rpc / kDo : og;
+      const int mbuf_next = og_next == og ? mbuf : mbuf ^ 1;
+      if (more) {
+        issue(next, v);
+        if (tid == 0) t_next = __hip_atomic_fetch_add(q_head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (og_next != og) mask_build(og_next, mbuf_next);
+        means(next, sbuf ^ 1);
+      }
+      if (tid == 0) sflag = t_next;
+      __syncthreads();                                 // next item's means / masks / the following ticket are visible
+      item = next;
+      next = sld(sflag);
+      sbuf ^= 1;
+      mbuf = mbuf_next;
+      og = og_next;
+      __syncthreads();                                 // (sflag may be rewritten)
+    }
+  }
+  // ---- leave: the last workgroup out zeroes the queue words for the next read (every workgroup comes through here)
+  if (tid == 0) {
+    const int gone = __hip_atomic_fetch_add(q_exit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gone == (int)gridDim.x - 1) {
+      __hip_atomic_store(q_head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(q_exit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 

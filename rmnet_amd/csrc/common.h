@@ -114,8 +114,10 @@ struct BankView {
   float* vpart;    // [no][Tcap][hwp/32][512] fp32: per 32-cell tile, the sum of the (un-scaled) values of its cells
   float* colsum;   // [no][Tcap][512] fp32: sum of a slot's values over the cells inside its box (bk_colsum)
   int32_t* area;   // [no][Tcap] cells inside the box of each memorised frame
-  int32_t* ovf;    // number of 16-byte groups written so far that held an element outside fp16's window
-  int32_t* cnt;    // [no][nqt_max] arrival tickets of the partials of an (object, query tile) pair; zero between reads
+  int32_t* ovf;    // control block (256 B): [0] number of 16-byte groups written so far that held an element outside fp16's
+                   // window; [16] / [32] the read kernel's static work queue (next item / workgroups gone)
+  int32_t* cnt;    // [no][nqt_max][2] (arrived, done) counters of the partials of an (object, query tile) pair
+                   // (all queue words and counters are zero between reads)
   int no, Tcap, h, w, hw, hwp;
 };
 BankView bank_view(void* base, int no, int Tcap, int h, int w);
