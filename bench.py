@@ -15,19 +15,21 @@ in HBM before the timed region.  With N ranks every rank runs its own clips (vid
 weak scaling, no data-path collective) and ``value`` = N * clips * K / max-over-ranks time.
 
 The JSON line also carries
-  roofline     -- the dominant hand-written kernel (bk_main, the regional memory read) timed live
-                  with HIP events recorded on its own stream around every launch of the timed
-                  region.  The kernel is bound by the matrix pipe under the chip's power cap (DESIGN.md
-                  section 5), so bound = "mfma": achieved = executed split-fp16 MFMA flops / mean
-                  duration vs the 2.5 PFLOP/s dense f16 peak.  BASELINE.json's headline figure --
-                  algorithmic bytes per launch / duration vs 8 TB/s HBM -- is kept beside it as
-                  roofline.hbm (frac = the kernel alone, op_frac = kernel + combine);
-  extras       -- single-stream and free-running (memorize_every = 5, N = 67, fed-back masks) fps, and
-                  kernel figures for BASELINE configs[2] / configs[4] and the other hand-written kernels,
-                  each against SURVEY.md section 8d's byte formulas (rank 0, N = 1 only);
+  roofline     -- the dominant hand-written kernel (bk_main = the WHOLE regional memory read: soft-max read,
+                  merge of the partial results, masked cells, the q_val half of the cat -- one launch)
+                  timed live with HIP events recorded on its own stream around every launch of the
+                  timed region.  achieved / peak / frac are SURVEY.md section 8d's figure: algorithmic
+                  bytes per launch / mean duration vs 8 TB/s HBM.  What actually bounds the kernel is the
+                  matrix pipe under the chip's power cap (DESIGN.md section 5), hence bound = "mfma";
+                  the pipe figures are in roofline.mfma (executed 3-term split-fp16 flops, useful
+                  one-term flops, the 2.5 PFLOP/s dense f16 peak);
+  extras       -- single-stream (eager and HIP-graph replay) and free-running (memorize_every = 5, N = 67,
+                  fed-back masks) fps; whole-loop frames/s for BASELINE configs[2] (5 objects), configs[4]
+                  (720p, 3 objects, T = 20) and the loader's K = 11 channel count; kernel figures for the
+                  hand-written kernels, each against SURVEY.md section 8d's byte formulas (rank 0, N = 1 only);
   cpu_baseline -- the oracle's CPU restatement of the same path timed on this box's host cores
-                  (rank 0, N = 1 only; bounded sample), plus the three native ops alone at all cores
-                  and at 8 threads.
+                  (rank 0, N = 1 only; bounded sample) at all cores and at 8 threads, plus the three
+                  native ops alone at both thread counts.
 """
 
 import argparse
@@ -130,11 +132,16 @@ def cpu_baseline(n_frames=3):
         att, _ = net.get_att_map(masks[:, t - 1], flow)
         return F.softmax(net.segment(frames[:, t], att, tk, tv, [K_CH - 1]), dim=1)
 
-    one_frame(T_MEM - 1)                                        # warm-up
-    t0 = time.perf_counter()
-    for i in range(n_frames):
-        one_frame(T_MEM + i)
-    dt = time.perf_counter() - t0
+    def timed(nt):
+        torch.set_num_threads(nt)
+        oracle.set_num_threads(nt)
+        one_frame(T_MEM - 1)                                    # warm-up
+        t0 = time.perf_counter()
+        for i in range(n_frames):
+            one_frame(T_MEM + i)
+        return time.perf_counter() - t0
+    dt8 = timed(min(8, all_threads))                            # n = 8 (the survey container's core count) ...
+    dt = timed(all_threads)                                     # ... and n = all cores
 
     # ---- the native ops alone
     g = torch.Generator().manual_seed(0)
@@ -166,9 +173,10 @@ def cpu_baseline(n_frames=3):
                    'itself on 8 vCPUs); region_map / flow_affine = oracle/rmnet_oracle.c (the reference runs flow_affine '
                    'single-threaded in DataLoader workers)')
     return {'value': round(n_frames / dt, 4), 'unit': 'frames/s', 'cores': all_threads, 'kind': 'port',
+            'value_8_threads': round(n_frames / dt8, 4),
             'sample': '%d frames of one 480x854 clip, 1 object, memory pinned at T=%d (4 committed frames pre-filled '
-                      'untimed), TinyFlowNet included, fp32, torch %d threads; %.1f s'
-                      % (n_frames, T_MEM, all_threads, dt),
+                      'untimed), TinyFlowNet included, fp32; torch %d threads: %.1f s, 8 threads: %.1f s'
+                      % (n_frames, T_MEM, all_threads, dt, dt8),
             'ops': ops}
 
 
@@ -236,10 +244,7 @@ def kernel_figures(dev, events):
             mm.append(events.elapsed_ms(e3[0], e3[1]) * 1e3 - floor)
             cc.append(events.elapsed_ms(e3[1], e3[2]) * 1e3 - floor)
         ab = algorithmic_bytes(no, T, h, w)
-        fig = gbs(ab, float(np.mean(mm)))
-        fig['combine_us'] = round(float(np.mean(cc)), 2)
-        fig['op_hbm_frac'] = round(ab / (np.mean(mm) + np.mean(cc)) / 1e3 / HBM_PEAK_GBS, 4)
-        out[name] = fig
+        out[name] = gbs(ab, float(np.mean(mm) + max(np.mean(cc), 0.0)))     # (one kernel = the whole op)
         if name.startswith('cfg3'):
             out['bk_append_5obj_480p'] = gbs(2 * 4 * (DE + DO) * h * w * no, bracket(lambda: bank.append(T - 1, k, v, r)))
         del bank
@@ -260,6 +265,39 @@ def kernel_figures(dev, events):
     out['flow_affine_480x854'] = gbs(16 * 480 * 854 + 48, bracket(lambda: ops.flow_affine(f, m1, m1)))
     out['event_floor_us'] = round(floor, 2)
     return out
+
+
+def loop_fps(net, tfn, dev, B, K, n_obj, H, W, T_mem, steps, seed0=100):
+    """Frames/s of the whole per-frame loop (TinyFlowNet + memorize + regional boxes + read + decoder + soft-max) for
+    another configuration: B clips of n_obj objects each in K mask channels, memory pinned at T_mem frames."""
+    from rmnet_amd.synthetic import synthetic_clip
+    n_clip = T_mem + 4
+    clips = [synthetic_clip(n_clip, n_obj + 1, H, W, seed=seed0 + c, size=2.1 if n_obj == 1 else 1.1) for c in range(B)]
+    frames = torch.cat([c[0] for c in clips]).to(dev)
+    masks = torch.cat([c[1] for c in clips]).to(dev).float()
+    if K > n_obj + 1:                                            # the reference's test loader: N_MAX_OBJECTS + 1 = 11 channels
+        masks = torch.cat([masks, torch.zeros(B, n_clip, K - n_obj - 1, H, W, device=dev)], dim=2)
+    ctx = net._ClipContext(net, B, K, H, W, [n_obj] * B, dev)
+    bank = net.new_bank(ctx, T_mem)
+    net._profile_events = None
+    for t in range(1, T_mem):
+        net.frame_step(ctx, bank, frames[:, t - 1], masks[:, t - 1], frames[:, t], tfn._forward(frames[:, t], frames[:, t - 1]), commit=True)
+
+    def step(i):
+        t = T_mem + (i % (n_clip - T_mem))
+        out = net.frame_step(ctx, bank, frames[:, t - 1], masks[:, t - 1], frames[:, t], tfn._forward(frames[:, t], frames[:, t - 1]), commit=False)
+        return out[1] if isinstance(out, tuple) else torch.softmax(out, dim=1)
+    for i in range(3):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert bool(torch.isfinite(out).all())
+    return {'fps': round(B * steps / dt, 2), 'ms_per_step': round(1e3 * dt / steps, 3), 'clips': B, 'objects_per_clip': n_obj,
+            'mask_channels': K, 'frame': '%dx%d' % (H, W), 'memory_frames': T_mem, 'steps': steps}
 
 
 def main():
@@ -406,9 +444,11 @@ def main():
                                want_map=False, cell_grid=(lw_, lh_, 16, ctx.h, ctx.w))
     qr = qr[:, 1].cpu()
     mq = (qr[:, 1] - qr[:, 0] + 1).clamp(min=0) * (qr[:, 3] - qr[:, 2] + 1).clamp(min=0)
-    nqt = (mq + 1 + 63) // 64
-    mfma_flops = float((nqt * 64 * njt * 32).sum()) * (DE + DO) * 2 * 3
+    nqt = (mq + 63) // 64
+    mfma_flops = float((nqt * 64 * njt * 32).sum()) * (DE + DO) * 2 * 3          # executed: 3 split terms over the padded tiles
     mfma_tflops = mfma_flops / (main_avg * 1e-3) / 1e12
+    useful_flops = float((mq * areas.sum(dim=1)).sum()) * (DE + DO) * 2          # one term over the un-padded regional cells
+    useful_tflops = useful_flops / (main_avg * 1e-3) / 1e12
     comb_avg = max(sum(comb_ms) / len(comb_ms) - ev_floor_us * 1e-3, 1e-6)
     op_achieved = abytes / ((main_avg + comb_avg) * 1e-3) / 1e9
     traffic, traffic_note = None, 'no PMC file for this kernel version'
@@ -416,7 +456,9 @@ def main():
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         if tj.get('source_hash') == source_hash() and int(tj.get('algorithmic_bytes_per_launch', -1)) == int(abytes):
-            traffic, traffic_note = tj.get('hbm_bytes_per_launch'), 'profiles/bk_main_hbm_traffic.json (same kernel sources, same workload)'
+            traffic = tj.get('hbm_bytes_per_launch')
+            traffic_note = ('profiles/bk_main_hbm_traffic.json (same kernel sources, same workload): FETCH_SIZE x 2 + WRITE_SIZE x 1, the '
+                            'factors calibrated on known byte counts in profiles/r03_power_ceiling.md')
         else:
             traffic_note = 'profiles/bk_main_hbm_traffic.json is from other kernel sources or another workload: not reported'
 
@@ -443,6 +485,41 @@ def main():
             step1(i)
         torch.cuda.synchronize()
         extras['single_stream_fps'] = round(20 / (time.perf_counter() - t1), 2)
+        # ---- the same single stream with the step (TinyFlowNet + frame_step) captured ONCE as a HIP graph and replayed
+        #      (SURVEY 8f-3): ~340 launches per frame become one graph launch + three input copies
+        try:
+            sb = [f1[:, T_MEM - 1].clone(), m1[:, T_MEM - 1].clone(), f1[:, T_MEM].clone()]
+
+            def body1():
+                o1 = net.frame_step(ctx1, bank1, sb[0], sb[1], sb[2], tfn._forward(sb[2], sb[0]), commit=False)
+                return o1[1] if isinstance(o1, tuple) else torch.softmax(o1, dim=1)
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                body1()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                o_static = body1()
+
+            def gstep(i):
+                t = T_MEM + (i % (n_clip - T_MEM))
+                sb[0].copy_(f1[:, t - 1]); sb[1].copy_(m1[:, t - 1]); sb[2].copy_(f1[:, t])
+                g1.replay()
+                return o_static
+            for i in range(5):
+                gstep(i)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(40):
+                gstep(i)
+            torch.cuda.synchronize()
+            extras['single_stream_graph_fps'] = round(40 / (time.perf_counter() - t1), 2)
+            assert bool(torch.isfinite(o_static).all())
+            del g1
+        except Exception as exc:                      # (capture support depends on the torch / ROCm build)
+            extras['single_stream_graph_fps'] = None
+            extras['single_stream_graph_error'] = repr(exc)[:300]
         # ---- free-running loop: RMNet.forward on one 67-frame clip (DAVIS-val mean length), memorize_every = 5,
         #      estimated masks fed back (the real feedback edge), TinyFlowNet inside the timed region
         from rmnet_amd.synthetic import synthetic_clip as _clip
@@ -452,15 +529,29 @@ def main():
         net(ff[:, :6], fm[:, :6], tfn(ff[:, :6]), fn_obj[:, :6], 5)          # warm-up
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        est = net(ff, fm, tfn(ff), fn_obj, 5)
+        est = net(ff, fm, tfn(ff), fn_obj, 5, graph=False)
         torch.cuda.synchronize()
         dt_free = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        est_g = net(ff, fm, tfn(ff), fn_obj, 5, graph=True)                  # RMNet.forward's default for clips >= 8 frames
+        torch.cuda.synchronize()
+        dt_free_g = time.perf_counter() - t1
         cover = float((est[0, 1:, 1] > 0.5).float().mean())
-        extras['free_running'] = {'fps': round((N_FREE - 1) / dt_free, 2), 'frames': N_FREE, 'memorize_every': 5,
+        extras['free_running'] = {'fps': round((N_FREE - 1) / dt_free, 2), 'fps_graph': round((N_FREE - 1) / dt_free_g, 2),
+                                  'graph_vs_eager_max_prob_diff': round(float((est - est_g).abs().max()), 6),
+                                  'frames': N_FREE, 'memorize_every': 5,
                                   'memory_frames_at_end': 14, 'clips': 1,
                                   'note': 'RMNet.forward + TinyFlowNet on one clip, masks fed back; with random-init weights the '
                                           'estimated object covers %.0f %% of the frame on average (boxes follow it)' % (100 * cover)}
-        del ff, est
+        del ff, est, est_g
+        # ---- whole-loop frames/s at the other BASELINE configurations: same step as the headline, other shapes
+        extras['loops'] = {
+            'cfg2_5obj_T5_480p_1clip': loop_fps(net, tfn, dev, 1, 6, 5, H, W, 5, 10),
+            'cfg2_5obj_T5_480p_4clips': loop_fps(net, tfn, dev, 4, 6, 5, H, W, 5, 6),
+            'cfg4_3obj_T20_720p_1clip': loop_fps(net, tfn, dev, 1, 4, 3, 720, 1280, 20, 6),
+            'loader_K11_1obj_T5_480p_8clips': loop_fps(net, tfn, dev, 8, 11, 1, H, W, 5, 10),
+            'note': 'memory pinned at T (T - 1 committed frames + the tentative previous frame); prev-frame masks = the synthetic '
+                    'blobs; K = 11 mirrors the reference test loader (config.py:137): 10 of the 11 channels are empty for a 1-object clip'}
         extras['kernels'] = kernel_figures(dev, events)
 
     if rank == 0:
@@ -483,28 +574,28 @@ def main():
                        'hip_graph': bool(args.graph), 'clips_per_gpu': B,
                        'batchnorm_folded': bool(args.fold_bn),
                        'fused_epilogues': bool(not args.fold_bn and not args.no_fuse_epilogue and not args.channels_last)},
-            'roofline': {'bound': 'mfma', 'kernel': 'bk_main (fused regional memory read, split-fp16 MFMA bank kernel)',
-                         'achieved': round(mfma_tflops, 1), 'peak': 2500.0, 'unit': 'TFLOP/s',
-                         'frac': round(mfma_tflops / 2500.0, 4), 'traffic': traffic, 'traffic_source': traffic_note,
-                         'why_mfma': 'three split-fp16 terms = 120 v_mfma_f32_16x16x32_f16 per SIMD per 64x32 tile; the chip is '
-                                     'power-capped under this load (shader clock 1.5-1.75 GHz inside the kernel, tools/bk_clk.py); a pure '
-                                     'random-data MFMA loop sustains 1.9 PFLOP/s (tools/ubench/mfma_power.hip); HBM traffic is ~0.25x the '
-                                     'algorithmic bytes',
-                         'flops_counted': 'executed: 3 split terms over the compacted 64-query x 32-cell tiles; the dense one-term algorithm '
-                                          '(SURVEY 8d: 2*THW*hw*(De+Do) per object-frame) would be %.1f TFLOP/s' %
-                                          (B * (K_CH - 1) * 2.0 * T_MEM * ctx.h * ctx.w * ctx.h * ctx.w * (DE + DO) / (main_avg * 1e-3) / 1e12),
-                         'hbm': {'note': "BASELINE.json's headline figure: SURVEY 8d algorithmic bytes per launch / duration vs 8 TB/s",
-                                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                                 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                                 'op_frac': round(op_achieved / HBM_PEAK_GBS, 4),
-                                 'algorithmic_bytes_per_launch': abytes},
+            'roofline': {'bound': 'mfma',
+                         'kernel': 'bk_main = the whole regional memory read in ONE launch (split-fp16 MFMA read of the bank, merge of the '
+                                   'partial results by the last workgroup of every query tile, masked cells, q_val half of the cat)',
+                         'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+                         'definition': 'SURVEY.md 8d / BASELINE.json: algorithmic bytes per launch (%d B = %d object-frames x 31,518,720 B) / '
+                                       'mean kernel duration, against 8 TB/s HBM' % (abytes, B * (K_CH - 1)),
+                         'traffic': traffic, 'traffic_source': traffic_note,
+                         'algorithmic_bytes_per_launch': abytes,
+                         'mfma': {'executed_3term_tflops': round(mfma_tflops, 1), 'useful_1term_tflops': round(useful_tflops, 1),
+                                  'dense_1term_tflops': round(B * (K_CH - 1) * 2.0 * T_MEM * ctx.h * ctx.w * ctx.h * ctx.w * (DE + DO) / (main_avg * 1e-3) / 1e12, 1),
+                                  'peak': 2500.0, 'unit': 'TFLOP/s', 'executed_frac_of_peak': round(mfma_tflops / 2500.0, 4),
+                                  'note': 'executed = 3 split-fp16 terms (hi*hi + hi*lo + lo*hi) over the compacted 64-query x 32-cell tiles incl. '
+                                          'padding; useful = one term over the un-padded regional cells; dense = SURVEY 8d '
+                                          '2*THW*hw*(De+Do) per object-frame as if nothing were masked.  The kernel is power-capped on the '
+                                          'matrix pipe (profiles/r03_power_ceiling.md): a pure random-data MFMA loop sustains 1.7-1.9 PFLOP/s'},
                          'launches': args.steps,
                          'avg_us': round(main_avg * 1e3, 2), 'avg_us_event_bracket': round(main_raw * 1e3, 2),
                          'event_floor_us': round(ev_floor_us, 2), 'min_us_event_bracket': round(min(main_ms) * 1e3, 2),
-                         'combine_avg_us': round(comb_avg * 1e3, 2),
-                         'op_avg_us': round((main_avg + comb_avg) * 1e3, 2),
-                         'timing': 'hipEventRecord on the launch stream around every bk_main / mr_combine of the timed region; '
-                                   'avg_us = bracket mean minus the empty-bracket floor measured the same way'},
+                         'op_avg_us': round((main_avg + comb_avg) * 1e3, 2), 'op_frac': round(op_achieved / HBM_PEAK_GBS, 4),
+                         'timing': 'hipEventRecord on the launch stream around every bk_main of the timed region; avg_us = bracket mean '
+                                   'minus the empty-bracket floor measured the same way (op_* adds the now empty second bracket where '
+                                   'round 2 had its combine kernel)'},
         }
         if extras is not None:
             line['extras'] = extras

@@ -165,6 +165,17 @@ size_t rmnet_bank_overflow_offset(int no, int Tcap, int h, int w);
 size_t rmnet_bank_area_offset(int no, int Tcap, int h, int w);
 int rmnet_bank_append_f32(void *bank, int no, int Tcap, int h, int w, int slot, const float *k4,
                           const float *v4, const int32_t *rects, void *stream);
+/* The same two calls with a DEVICE-RESIDENT frame counter (int32, may be NULL): the slot written is slot + *slot_dev,
+ * the frames read are T + *T_dev (clamped to [1, Tcap]).  The host need not know how long the memory is, so one
+ * captured HIP graph of the frame loop (models/rmnet.py:410-450: memorise frame t-1 into slot `committed`, read
+ * committed + 1 frames) can be replayed for every frame while the counter is bumped by a one-element add between
+ * replays. */
+int rmnet_bank_append_f32_at(void *bank, int no, int Tcap, int h, int w, int slot, const int32_t *slot_dev,
+                             const float *k4, const float *v4, const int32_t *rects, void *stream);
+int rmnet_bank_read_f32_at(void *bank, int no, int Tcap, int h, int w, int T, const int32_t *T_dev,
+                           const float *q_key, const float *q_val, const int32_t *qry_rects,
+                           float *mem_val, void *workspace, size_t workspace_bytes, void *stream,
+                           void *ev_start, void *ev_mid, void *ev_end);
 size_t rmnet_bank_read_workspace_bytes(int no, int h, int w);
 int rmnet_bank_read_f32(void *bank, int no, int Tcap, int h, int w, int T,
                         const float *q_key, const float *q_val, const int32_t *qry_rects,

@@ -47,6 +47,13 @@ SIGNATURES = {
     'rmnet_bank_append_f32': (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p,
         c_f32p, c_i32p, ctypes.c_void_p]),
+    'rmnet_bank_append_f32_at': (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i32p, c_f32p,
+        c_f32p, c_i32p, ctypes.c_void_p]),
+    'rmnet_bank_read_f32_at': (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i32p, c_f32p,
+        c_f32p, c_i32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p]),
     'rmnet_bank_read_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 3),
     'rmnet_bank_read_f32': (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p,

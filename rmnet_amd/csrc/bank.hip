@@ -154,13 +154,17 @@ namespace {
 // frame f of the source: element (o, c, f, cell) of k4 at o * k_os + c * k_cs + f * hw + cell (same for
 // v4).  The frame loop appends one frame of contiguous [no,C,h,w] tensors (nf = 1, k_cs = hw); the
 // drop-in MemoryReader entry stages all T frames of a [no,C,T,h,w] memory in one launch.
-__global__ __launch_bounds__(kThreads) void bk_append(BankView b, int slot0, int nf,
+__global__ __launch_bounds__(kThreads) void bk_append(BankView b, int slot0, const int32_t* __restrict__ slot_dev, int nf,
                                                       const float* __restrict__ k4,
                                                       const float* __restrict__ v4, long long k_cs,
                                                       long long k_os, long long v_cs, long long v_os,
                                                       const int32_t* __restrict__ rects) {
   __shared__ float tile[kJT][kDe + 1];
   const int u = blockIdx.x, tid = threadIdx.x;
+  // slot_dev (optional): a device-resident frame counter added to slot0 -- lets a captured HIP graph of the frame
+  // loop be replayed while the memory grows (the host never has to bake the slot into a kernel argument)
+  if (slot_dev) slot0 += __builtin_amdgcn_readfirstlane(*slot_dev);
+  if (slot0 < 0 || slot0 + nf > b.Tcap) return;      // (a full bank: the host-side bookkeeping raises before this can happen)
   const int o = (int)blockIdx.y / nf, f = (int)blockIdx.y - o * nf, slot = slot0 + f;
   Rect rc{0, b.w - 1, 0, b.h - 1};
   if (rects) {
@@ -256,7 +260,9 @@ __global__ __launch_bounds__(kThreads) void bk_append(BankView b, int slot0, int
 }
 
 // grid = no * nf blocks of kDo threads: slot (o, slot0 + f)'s column sums = its tiles' sums in tile order.
-__global__ __launch_bounds__(kDo) void bk_colsum(BankView b, int slot0, int nf) {
+__global__ __launch_bounds__(kDo) void bk_colsum(BankView b, int slot0, const int32_t* __restrict__ slot_dev, int nf) {
+  if (slot_dev) slot0 += __builtin_amdgcn_readfirstlane(*slot_dev);
+  if (slot0 < 0 || slot0 + nf > b.Tcap) return;
   const int o = (int)blockIdx.x / nf, f = (int)blockIdx.x - o * nf, d = threadIdx.x;
   const size_t so = (size_t)o * b.Tcap + slot0 + f;
   const int ntiles = (b.area[so] + kJT - 1) / kJT;
@@ -276,6 +282,7 @@ struct BArgs {
   float* ws_ml;              // [no][slots][2][kQT]: running reference (log2 domain) and sum
   int32_t* ws_plan;          // [no][kPlanInts]
   int T;
+  const int32_t* T_dev;      // optional: device-resident frame counter added to T (graph replay while the memory grows)
   int trace_slot;            // BK_TRACE builds: the (unused) last partial slot receives the cycle stamps
   int gate;                  // != 0: do nothing when the bank's overflow word is set (mr_main then runs instead)
   int obj0, nobj;            // objects [obj0, obj0 + nobj) belong to this launch (nobj <= kMaxObj)
@@ -816,6 +823,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
 #endif
   const int ng = a.nobj;
   const int hw = b.hw;
+  const int T_ = min(max(a.T + (a.T_dev ? __builtin_amdgcn_readfirstlane(*a.T_dev) : 0), 1), b.Tcap);   // memorised frames to read
   int* q_head = b.ovf + 16;                        // control block of the bank: static work queue (next item) ...
   int* q_exit = b.ovf + 32;                        // ... workgroups that have left the kernel (the last one zeroes both)
 
@@ -825,10 +833,10 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   // Fast path (<= 12 objects, <= 64 memorised frames): wave w owns object w, lane t its frame t; the
   // areas stay in registers, so the owner wave later builds the object's tile prefix without a
   // second trip to memory.  Otherwise: LDS atomics now, a reload of the object's areas later.
-  const bool fastplan = ng <= kProducers + kConsumers && a.T <= RMNET_WAVE;
+  const bool fastplan = ng <= kProducers + kConsumers && T_ <= RMNET_WAVE;
   int my_ar = 0;
   if (fastplan) {
-    if (wave < ng && lane0 < a.T) my_ar = b.area[(size_t)(a.obj0 + wave) * b.Tcap + lane0];
+    if (wave < ng && lane0 < T_) my_ar = b.area[(size_t)(a.obj0 + wave) * b.Tcap + lane0];
   } else if (tid < ng) {
     o_njt[tid] = 0; o_m[tid] = 0;
   }
@@ -848,8 +856,8 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     if (lane0 == 0 && wave < ng) { o_njt[wave] = tiles; o_m[wave] = cells; }
   } else {
     __syncthreads();
-    for (int idx = tid; idx < ng * a.T; idx += kRThreads) {
-      const int og = idx / a.T, t = idx - og * a.T;
+    for (int idx = tid; idx < ng * T_; idx += kRThreads) {
+      const int og = idx / T_, t = idx - og * T_;
       const int ar = b.area[(size_t)(a.obj0 + og) * b.Tcap + t];
       atomicAdd(&o_njt[og], (ar + kJT - 1) / kJT);
       atomicAdd(&o_m[og], ar);
@@ -914,7 +922,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   wk.qr = Rect{sld(o_rect[og][0]), sld(o_rect[og][1]), sld(o_rect[og][2]), sld(o_rect[og][3])};
   wk.Mq = wk.qr.area();
   const int slot_obj = a.slot0 + sld(o_sb[og]);
-  const float n_out = (float)(a.T * hw - sld(o_m[og]));      // masked memory cells: S = 0, V = 0 (file header)
+  const float n_out = (float)(T_ * hw - sld(o_m[og]));      // masked memory cells: S = 0, V = 0 (file header)
 
   // ---- this object's tile prefix over the T memorised frames
   if (fastplan) {
@@ -925,21 +933,21 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
         const int up = __shfl_up(sc, d);
         if (lane0 >= d) sc += up;
       }
-      if (lane0 < a.T) { tpre[lane0 + 1] = sc; tarea[lane0] = my_ar; }
+      if (lane0 < T_) { tpre[lane0 + 1] = sc; tarea[lane0] = my_ar; }
       if (lane0 == 0) tpre[0] = 0;
     }
   } else if (tid < RMNET_WAVE) {
     int carry = 0;
-    for (int base = 0; base < a.T; base += RMNET_WAVE) {
+    for (int base = 0; base < T_; base += RMNET_WAVE) {
       const int t = base + tid;
-      const int ar = t < a.T ? b.area[(size_t)wk.o * b.Tcap + t] : 0;
+      const int ar = t < T_ ? b.area[(size_t)wk.o * b.Tcap + t] : 0;
       int sc = (ar + kJT - 1) / kJT;
 #pragma unroll
       for (int d = 1; d < RMNET_WAVE; d <<= 1) {
         const int up = __shfl_up(sc, d);
         if (tid >= d) sc += up;
       }
-      if (t < a.T) { tpre[t + 1] = carry + sc; tarea[t] = ar; }
+      if (t < T_) { tpre[t + 1] = carry + sc; tarea[t] = ar; }
       carry += __shfl(sc, RMNET_WAVE - 1);
     }
     if (tid == 0) tpre[0] = 0;
@@ -949,7 +957,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   // One segment = the tile walk (producer / consumer roles) + its epilogue.  `sself` = this segment's position in
   // the pair's slot list.
   auto run_segment = [&](int sself) {
-    int lo = 0, hi = a.T;   // frame of the first tile
+    int lo = 0, hi = T_;   // frame of the first tile
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
       if (sld(tpre[mid]) <= wk.jt0) lo = mid; else hi = mid;
@@ -1227,7 +1235,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     const int nunits = rpc * hwv;                                            // <= kB * kRThreads unless one row alone is longer
     const float* __restrict__ qv0 = a.qv + (size_t)a.obj0 * kDo * hw;      // rows (og, d) of the launch, contiguous
     float* __restrict__ out0 = a.out + (size_t)a.obj0 * 2 * kDo * hw;
-    const float inv_cells = 1.0f / ((float)a.T * (float)hw);
+    const float inv_cells = 1.0f / ((float)T_ * (float)hw);
     const int step_row = kRThreads / hwv, step_cu = kRThreads - step_row * hwv;
     unsigned char* umask = reinterpret_cast<unsigned char*>(Kl_);          // [2][hwv] (the K ring is idle here)
     float* smean2 = reinterpret_cast<float*>(Kl_ + 2 * ((hwv + 15) & ~15));  // [2][kStaticRows]
@@ -1246,7 +1254,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
       for (int ra = wave; ra < rpc; ra += 2 * (kProducers + kConsumers)) {
         const int rb = ra + kProducers + kConsumers;
         float pa = 0.0f, pb = 0.0f;
-        for (int t = lane0; t < a.T; t += RMNET_WAVE) {
+        for (int t = lane0; t < T_; t += RMNET_WAVE) {
           pa += cs0[(size_t)t * kDo + ra];
           if (rb < rpc) pb += cs0[(size_t)t * kDo + rb];
         }
@@ -1364,23 +1372,23 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
 }  // namespace
 
 int launch_bank_append(void* bank, int no, int Tcap, int h, int w, int slot, const float* k4,
-                       const float* v4, const int32_t* rects, hipStream_t st) {
+                       const float* v4, const int32_t* rects, hipStream_t st, const int32_t* slot_dev) {
   const long long hw = (long long)h * w;
-  return launch_bank_stage(bank, no, Tcap, h, w, slot, 1, k4, v4, hw, hw * kDe, hw, hw * kDo, rects, st);
+  return launch_bank_stage(bank, no, Tcap, h, w, slot, 1, k4, v4, hw, hw * kDe, hw, hw * kDo, rects, st, slot_dev);
 }
 
 int launch_bank_stage(void* bank, int no, int Tcap, int h, int w, int slot0, int nf, const float* k4,
                       const float* v4, long long k_cs, long long k_os, long long v_cs, long long v_os,
-                      const int32_t* rects, hipStream_t st) {
+                      const int32_t* rects, hipStream_t st, const int32_t* slot_dev) {
   if (!bank || !k4 || !v4 || no <= 0 || Tcap <= 0 || h <= 0 || w <= 0 || nf <= 0 || slot0 < 0 ||
       slot0 + nf > Tcap)
     return RMNET_E_INVALID_ARG;
   if ((long long)no * nf > 65535 || Tcap > kMaxT) return RMNET_E_UNSUPPORTED;
   const BankView b = bank_view(bank, no, Tcap, h, w);
-  hipLaunchKernelGGL(bk_append, dim3(b.hwp / kJT, no * nf, 1 + kDo / kDe), dim3(kThreads), 0, st, b, slot0, nf,
+  hipLaunchKernelGGL(bk_append, dim3(b.hwp / kJT, no * nf, 1 + kDo / kDe), dim3(kThreads), 0, st, b, slot0, slot_dev, nf,
                      k4, v4, k_cs, k_os, v_cs, v_os, rects);
   if (int e = check_launch()) return e;
-  hipLaunchKernelGGL(bk_colsum, dim3(no * nf), dim3(kDo), 0, st, b, slot0, nf);
+  hipLaunchKernelGGL(bk_colsum, dim3(no * nf), dim3(kDo), 0, st, b, slot0, slot_dev, nf);
   return check_launch();
 }
 
@@ -1393,6 +1401,7 @@ int launch_bank_main(const BankReadArgs& m, hipStream_t st) {
   a.out = m.out;
   a.ws_o = m.ws_o; a.ws_ml = m.ws_ml; a.ws_plan = m.ws_plan;
   a.T = m.T;
+  a.T_dev = m.T_dev;
   a.gate = m.gate;
   a.trace_slot = m.slots - 1;
   a.qscale = 1.44269504088896341f / sqrtf((float)kDe) * kBankScale;   // (the un-scaling is kSraw in the soft-max)

@@ -97,6 +97,11 @@ int rmnet_bank_append_f32(void* bank, int no, int Tcap, int h, int w, int slot, 
   return launch_bank_append(bank, no, Tcap, h, w, slot, k4, v4, rects, static_cast<hipStream_t>(stream));
 }
 
+int rmnet_bank_append_f32_at(void* bank, int no, int Tcap, int h, int w, int slot, const int32_t* slot_dev,
+                             const float* k4, const float* v4, const int32_t* rects, void* stream) {
+  return launch_bank_append(bank, no, Tcap, h, w, slot, k4, v4, rects, static_cast<hipStream_t>(stream), slot_dev);
+}
+
 size_t rmnet_bank_read_workspace_bytes(int no, int h, int w) {
   if (no <= 0 || h <= 0 || w <= 0) return 0;
   return bank_read_ws_bytes(no, h, w);
@@ -108,6 +113,21 @@ int rmnet_bank_read_f32(void* bank, int no, int Tcap, int h, int w, int T, const
                         void* ev_mid, void* ev_end) {
   BankReadArgs a;
   a.bank = bank; a.no = no; a.Tcap = Tcap; a.h = h; a.w = w; a.T = T;
+  a.qk = q_key; a.qv = q_val; a.qry_rects = qry_rects; a.out = mem_val;
+  a.ws_o = nullptr; a.ws_ml = nullptr; a.ws_plan = nullptr; a.slots = 0;
+  a.ws = workspace; a.ws_bytes = workspace_bytes;
+  a.ev_start = static_cast<hipEvent_t>(ev_start);
+  a.ev_mid = static_cast<hipEvent_t>(ev_mid);
+  a.ev_end = static_cast<hipEvent_t>(ev_end);
+  return launch_bank_read(a, static_cast<hipStream_t>(stream));
+}
+
+int rmnet_bank_read_f32_at(void* bank, int no, int Tcap, int h, int w, int T, const int32_t* T_dev,
+                           const float* q_key, const float* q_val, const int32_t* qry_rects, float* mem_val,
+                           void* workspace, size_t workspace_bytes, void* stream, void* ev_start, void* ev_mid,
+                           void* ev_end) {
+  BankReadArgs a;
+  a.bank = bank; a.no = no; a.Tcap = Tcap; a.h = h; a.w = w; a.T = T; a.T_dev = T_dev;
   a.qk = q_key; a.qv = q_val; a.qry_rects = qry_rects; a.out = mem_val;
   a.ws_o = nullptr; a.ws_ml = nullptr; a.ws_plan = nullptr; a.slots = 0;
   a.ws = workspace; a.ws_bytes = workspace_bytes;

@@ -210,12 +210,13 @@ struct BankReadArgs {
   size_t ws_bytes;
   hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_end = nullptr;
   int gate = 0;               // != 0: bk_main returns at once when the bank's overflow word is set
+  const int32_t* T_dev = nullptr;   // optional device-resident frame counter added to T
 };
 int launch_bank_append(void* bank, int no, int Tcap, int h, int w, int slot, const float* k4,
-                       const float* v4, const int32_t* rects, hipStream_t st);
+                       const float* v4, const int32_t* rects, hipStream_t st, const int32_t* slot_dev = nullptr);
 int launch_bank_stage(void* bank, int no, int Tcap, int h, int w, int slot0, int nf, const float* k4,
                       const float* v4, long long k_cs, long long k_os, long long v_cs, long long v_os,
-                      const int32_t* rects, hipStream_t st);   // nf frames of a strided [no,C,T,h,w] source
+                      const int32_t* rects, hipStream_t st, const int32_t* slot_dev = nullptr);   // nf frames of a strided [no,C,T,h,w] source
 size_t bank_overflow_offset(int no, int Tcap, int h, int w);
 int launch_bank_main(const BankReadArgs& a, hipStream_t st);   // bank.hip: the whole read (one launch per 64 objects)
 size_t bank_read_ws_bytes(int no, int h, int w);

@@ -888,7 +888,7 @@ size_t bank_read_ws_bytes(int no, int h, int w) {
 
 int launch_bank_read(BankReadArgs& m, hipStream_t st) {
   if (!m.bank || !m.qk || !m.qv || !m.out) return RMNET_E_INVALID_ARG;
-  if (m.no <= 0 || m.Tcap <= 0 || m.h <= 0 || m.w <= 0 || m.T <= 0 || m.T > m.Tcap)
+  if (m.no <= 0 || m.Tcap <= 0 || m.h <= 0 || m.w <= 0 || m.T > m.Tcap || (m.T <= 0 && !m.T_dev) || m.T < 0)
     return RMNET_E_INVALID_ARG;
   if (m.no > 65535 || m.Tcap > kMaxT) return RMNET_E_UNSUPPORTED;
   if (!m.ws || m.ws_bytes < bank_read_ws_bytes(m.no, m.h, m.w)) return RMNET_E_WORKSPACE;

@@ -181,6 +181,9 @@ class MemoryBank:
             raise RuntimeError('invalid bank geometry')
         with torch.cuda.device(self.device):
             self.blob = torch.zeros(nb, dtype=torch.uint8, device=self.device)
+            # device-resident copy of `committed`: stage() / read_staged() hand it to the kernels, so a captured HIP graph
+            # of the frame step stays valid while the memory grows (rmnet_bank_*_at in include/rmnet_hip.h)
+            self.n_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.committed = 0
 
     def append(self, slot, k4, v4, rects=None):
@@ -212,16 +215,34 @@ class MemoryBank:
 
     def stage(self, k4, v4, rects):
         """Write one frame into the first free slot without committing it (the tentative previous
-        frame of models/rmnet.py:416-426).  Returns the number of frames visible to ``read``."""
+        frame of models/rmnet.py:416-426).  Returns the number of frames visible to ``read``.  The slot index
+        travels as the device counter ``n_dev`` (graph-replayable); ``committed`` mirrors it on the host."""
         if self.committed >= self.capacity:
             raise RuntimeError('memory bank overflow (%d slots)' % self.capacity)
-        self.append(self.committed, k4, v4, rects)
+        _check(k4, 'k4')
+        _check(v4, 'v4')
+        if tuple(k4.shape) != (self.no, 128, self.h, self.w) or tuple(v4.shape) != (self.no, 512, self.h, self.w):
+            raise RuntimeError('k4/v4 must be [no,128,h,w] / [no,512,h,w]')
+        if rects is not None:
+            _check(rects, 'rects', torch.int32)
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            rc = lib.rmnet_bank_append_f32_at(_ptr(self.blob), self.no, self.capacity, self.h, self.w, 0, _ptr(self.n_dev),
+                                              _ptr(k4), _ptr(v4), _ptr(rects), _stream(self.device))
+        _lib.check(rc, 'rmnet_bank_append_f32_at')
         return self.committed + 1
 
     def commit(self):
+        """Keep the staged frame: one-element add on the device counter (after the read that used it as tentative)."""
         self.committed += 1
+        self.n_dev += 1
 
-    def read(self, T, q_key, q_val, qry_rects=None, out=None, events=None, ws=None):
+    def read_staged(self, q_key, q_val, qry_rects=None, out=None, events=None, ws=None):
+        """``read(committed + 1, ...)`` with the frame count taken from the device counter (committed frames + the
+        staged one): the call a captured graph replays."""
+        return self.read(1, q_key, q_val, qry_rects, out=out, events=events, ws=ws, _t_dev=self.n_dev)
+
+    def read(self, T, q_key, q_val, qry_rects=None, out=None, events=None, ws=None, _t_dev=None):
         _check(q_key, 'q_key')
         _check(q_val, 'q_val')
         if tuple(q_key.shape) != (self.no, 128, self.h, self.w) or tuple(q_val.shape) != (self.no, 512, self.h, self.w):
@@ -237,10 +258,10 @@ class MemoryBank:
             if ws is None:
                 ws = _ws(lib.rmnet_bank_read_workspace_bytes(self.no, self.h, self.w), self.device)
             ev = [ctypes.c_void_p(e) if e else None for e in (events or (None, None, None))]
-            rc = lib.rmnet_bank_read_f32(_ptr(self.blob), self.no, self.capacity, self.h, self.w, int(T),
-                                         _ptr(q_key), _ptr(q_val), _ptr(qry_rects), _ptr(out), _ptr(ws),
-                                         ws.numel(), _stream(self.device), ev[0], ev[1], ev[2])
-        _lib.check(rc, 'rmnet_bank_read_f32')
+            rc = lib.rmnet_bank_read_f32_at(_ptr(self.blob), self.no, self.capacity, self.h, self.w, int(T), _ptr(_t_dev),
+                                            _ptr(q_key), _ptr(q_val), _ptr(qry_rects), _ptr(out), _ptr(ws),
+                                            ws.numel(), _stream(self.device), ev[0], ev[1], ev[2])
+        _lib.check(rc, 'rmnet_bank_read_f32_at')
         return out
 
 
@@ -248,7 +269,7 @@ class TensorBank:
     """Same interface as ``MemoryBank`` on plain fp32 tensors in the reference's layout
     ([no,C,Tcap,h,w] + cell rectangles), read with the exact-fp32 kernel: no limit on the number of
     slots, no limit on the value range, about 4x slower.  The frame loop switches to it for clips with
-    more than 512 memorised frames and when a ``MemoryBank`` reported out-of-window values."""
+    more than 2048 memorised frames and when a ``MemoryBank`` reported out-of-window values."""
 
     def __init__(self, no, capacity, h, w, device):
         self.no, self.capacity, self.h, self.w = int(no), int(capacity), int(h), int(w)
@@ -281,13 +302,23 @@ class TensorBank:
     def commit(self):
         self.committed += 1
 
+    def read_staged(self, q_key, q_val, qry_rects=None, out=None, events=None, ws=None):
+        return self.read(self.committed + 1, q_key, q_val, qry_rects, out=out, events=events, ws=ws)
+
     def read(self, T, q_key, q_val, qry_rects=None, out=None, events=None, ws=None):
         if qry_rects is None:
             qry_rects = torch.tensor([[0, self.w - 1, 0, self.h - 1]] * self.no, dtype=torch.int32, device=self.device)
         out, _ = memory_read(self.m_key, self.m_val, q_key, q_val, self.rects[:, :T].contiguous(),
                              qry_rects.contiguous(), T=T, out=out, events=events,
-                             flags=MR_EXACT_FP32 if T <= BANK_MAX_SLOTS else MR_FORCE_GENERIC)
+                             flags=MR_EXACT_FP32 if T <= BANK_MAX_SLOTS else self._generic_flags(T))
         return out
+
+    def _generic_flags(self, T):
+        import warnings
+        nbytes = self.no * T * (self.h * self.w) ** 2 * 4
+        warnings.warn('rmnet_amd: %d memorised frames exceed the fused kernels (%d): falling back to the generic path, which '
+                      'materialises the affinity (%.1f GB of workspace)' % (T, BANK_MAX_SLOTS, nbytes / 1e9))
+        return MR_FORCE_GENERIC
 
 
 def rect_mask(x, rects):

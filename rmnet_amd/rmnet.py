@@ -245,7 +245,10 @@ class RMNet(nn.Module):
             r3e, r2e = r3.index_select(0, batch_of_obj), r2.index_select(0, batch_of_obj)
         ev = getattr(self, '_profile_events', None)
         if isinstance(m_key, (ops.MemoryBank, ops.TensorBank)):   # the frame loop: pre-compacted split-fp16 bank
-            m4 = m_key.read(T, k4e.contiguous(), v4e.contiguous(), qry_rects, events=ev)
+            if T is None:                               # committed frames + the staged one, counted on the device
+                m4 = m_key.read_staged(k4e.contiguous(), v4e.contiguous(), qry_rects, events=ev)
+            else:
+                m4 = m_key.read(T, k4e.contiguous(), v4e.contiguous(), qry_rects, events=ev)
         else:                                       # reference-layout fp32 tensors (public segment())
             m4, _ = ops.memory_read(m_key, m_val, k4e.contiguous(), v4e.contiguous(), mem_rects, qry_rects,
                                     T=T, events=ev)
@@ -303,13 +306,13 @@ class RMNet(nn.Module):
         """One iteration of models/rmnet.py:410-433: memorise frame t-1 (tentatively, or for good
         when ``commit``), derive the regional query boxes from the flow-warped previous mask, segment
         frame t.  Returns the logits [B,K,H,W] -- or, after ``fuse_epilogues()``, the pair
-        (logits, soft-max over K of the logits).  No host synchronisation."""
+        (logits, soft-max over K of the logits).  No host synchronisation, and no frame-dependent kernel argument
+        (the bank's slot / frame count travel as a device counter): with ``commit=False`` the step can be captured
+        into a HIP graph once and replayed for every frame (``forward`` does)."""
         self._inference_only()
         B, K = ctx.B, ctx.K
         k4, v4, boxes, rects = self._encode_memory(prev_frame, prev_mask, ctx.n_max)
-        T = bank.stage(k4.contiguous(), v4.contiguous(), rects.view(B * K, 4).index_select(0, ctx.flat))
-        if commit:
-            bank.commit()
+        bank.stage(k4.contiguous(), v4.contiguous(), rects.view(B * K, 4).index_select(0, ctx.flat))
         if getattr(self, '_fused_tail', False) and self._fused_warp_ok(prev_mask.device):   # warp fused into the box reduction
             _, _, q_rects = ops.region_map(prev_mask.contiguous(), want_map=False, flow=cur_flow.contiguous(),
                                            cell_grid=(ctx.lw, ctx.lh, 16, ctx.h, ctx.w))
@@ -318,14 +321,24 @@ class RMNet(nn.Module):
             _, _, q_rects = ops.region_map(expt.contiguous(), want_map=False,
                                            cell_grid=(ctx.lw, ctx.lh, 16, ctx.h, ctx.w))
         q_rects = q_rects.view(B * K, 4).index_select(0, ctx.flat)
-        return self._segment_core(cur_frame, q_rects, bank, None, None, T, ctx.n_max, K, ctx.batch_of_obj,
-                                  obj_begin=ctx.obj_begin)
+        out = self._segment_core(cur_frame, q_rects, bank, None, None, None, ctx.n_max, K, ctx.batch_of_obj,
+                                 obj_begin=ctx.obj_begin)
+        if commit:          # AFTER the read: the frame count lives on the device (bank.n_dev), the read used committed + 1
+            bank.commit()
+        return out
 
     @torch.no_grad()
-    def forward(self, frames, masks, optical_flows, n_objects, memorize_every, device=None, _exact=False):
+    def forward(self, frames, masks, optical_flows, n_objects, memorize_every, device=None, _exact=False, graph=None):
         """models/rmnet.py:385-452.  frames [B,N,3,H,W] f32, masks [B,N,K,H,W] (one-hot, any int or
         float dtype), optical_flows [B,N,2,H,W] f32, n_objects [B,N] int -> est_masks [B,N,K,H,W]
-        f32 on the GPU (the reference returns them on the host unless several GPUs are visible)."""
+        f32 on the GPU (the reference returns them on the host unless several GPUs are visible).
+
+        ``graph``: replay the frame step as ONE captured HIP graph instead of ~340 launches per frame.
+        None (default) = yes for clips of 8 frames or more on the split-fp16 bank; the first segmented frame always runs
+        eagerly (it warms MIOpen up and runs the fused-warp self-check), the graph is captured on the second.  The step has
+        no frame-dependent kernel argument -- the memory length lives in a device counter -- so one capture serves the
+        whole clip; only the copies into its static input buffers, the commit increment and the rare logit edits of
+        models/rmnet.py:436-448 happen outside it."""
         self._inference_only()
         dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         frames = frames.to(dev, non_blocking=True)
@@ -345,9 +358,21 @@ class RMNet(nn.Module):
         ctx = self._ClipContext(self, B, K, H, W, n_max, dev)
         bank = self.new_bank(ctx, sum(1 for j in commit if j <= N - 2) + 1, exact=_exact)
 
+        use_graph = (N >= 8 if graph is None else bool(graph)) and isinstance(bank, ops.MemoryBank)
+        replay = None
         for t in range(1, N):
-            logit = self.frame_step(ctx, bank, frames[:, t - 1], est[:, t - 1], frames[:, t],
-                                    optical_flows[:, t], (t - 1) in commit)
+            if use_graph and t >= 2:
+                if replay is None:
+                    replay = self._capture_frame_step(ctx, bank, frames[:, t - 1], est[:, t - 1], frames[:, t], optical_flows[:, t])
+                    if replay is None:
+                        use_graph = False
+            if use_graph and t >= 2:
+                logit = replay(frames[:, t - 1], est[:, t - 1], frames[:, t], optical_flows[:, t])
+                if (t - 1) in commit:
+                    bank.commit()
+            else:
+                logit = self.frame_step(ctx, bank, frames[:, t - 1], est[:, t - 1], frames[:, t],
+                                        optical_flows[:, t], (t - 1) in commit)
             prob = None
             if isinstance(logit, tuple):
                 logit, prob = logit     # fused tail: soft-max already done (valid if the logits stay as they are)
@@ -367,3 +392,37 @@ class RMNet(nn.Module):
         if bank.overflow_count():   # (one host sync per clip) K/V outside the split-fp16 window: redo the clip exactly
             return self.forward(frames, masks, optical_flows, n_objects, memorize_every, device=dev, _exact=True)
         return est
+
+    def _capture_frame_step(self, ctx, bank, prev_frame, prev_mask, cur_frame, cur_flow):
+        """Capture ``frame_step(commit=False)`` on static copies of its four inputs; returns ``replay(prev_frame,
+        prev_mask, cur_frame, cur_flow) -> frame_step's return value`` (static output tensors: consume them before the
+        next replay), or None when this torch / ROCm build cannot capture the step (the loop then stays eager)."""
+        dev = prev_frame.device
+        saved_events = getattr(self, '_profile_events', None)
+        self._profile_events = None                    # hipEventRecord on a capturing stream is not what a profiler wants
+        try:
+            bufs = [prev_frame.clone(), prev_mask.clone(), cur_frame.clone(), cur_flow.clone()]
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):              # warm-up on a side stream, as torch's capture rules ask
+                self.frame_step(ctx, bank, *bufs, commit=False)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self.frame_step(ctx, bank, *bufs, commit=False)
+        except Exception as exc:                       # pragma: no cover - depends on the torch / ROCm build
+            import warnings
+            warnings.warn('rmnet_amd: HIP graph capture of the frame step failed (%s); running eagerly' % (exc,))
+            return None
+        finally:
+            self._profile_events = saved_events
+
+        def replay(pf, pm, cf, fl):
+            bufs[0].copy_(pf)
+            bufs[1].copy_(pm)
+            bufs[2].copy_(cf)
+            bufs[3].copy_(fl)
+            g.replay()
+            return out
+        replay.graph = g
+        return replay

@@ -1375,3 +1375,24 @@ def test_memory_longer_than_512_frames(oracle_mod):
     for flags in (0, ops.MR_EXACT_FP32):
         got, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), cu(mr), cu(qr), flags=flags)
         np.testing.assert_allclose(got.cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL)
+
+
+def test_forward_replays_one_hip_graph_for_the_whole_clip(oracle_mod):
+    """RMNet.forward captures the frame step once (second segmented frame) and replays it while the memory
+    grows -- the bank's slot / frame count are a DEVICE counter, not kernel arguments.  A 10-frame clip with memorize_every = 3
+    (the memory grows from 1 to 4 frames under replay) and an object that appears mid-clip (logit edits outside the graph):
+    graph == eager == CPU path."""
+    prod, ref = _nets(oracle_mod)
+    prod.fuse_epilogues()
+    frames, masks, flows, n_objects = _clip_with_late_object(10, 96, 160, seed=31)
+    captured = []
+    orig = prod._capture_frame_step
+    prod._capture_frame_step = lambda *a, **k: (captured.append(1), orig(*a, **k))[1]
+    with torch.no_grad():
+        est_g = prod(frames, masks, flows, n_objects, 3, graph=True).cpu()
+        est_e = prod(frames, masks, flows, n_objects, 3, graph=False).cpu()
+        est_cpu = ref(frames, masks, flows, n_objects, 3)
+    assert captured == [1]                                        # one capture, nine replays
+    assert float((est_g - est_e).abs().max()) < 1e-3            # (MIOpen may pick another algorithm under capture)
+    assert float((est_g - est_cpu).abs().max()) < 1e-3
+    assert (est_g.argmax(2) == est_cpu.argmax(2)).float().mean() > 0.999

@@ -255,3 +255,66 @@ def test_compat_registers_the_reference_module_names():
             sys.path.remove(ref)
             for k in [k for k in sys.modules if k == 'extensions' or k.startswith('extensions.') or k == 'utils' or k.startswith('utils.')]:
                 del sys.modules[k]
+
+
+# YouTube-VOS-shaped variety (BASELINE configs[3]): mixed 480p / 720p label maps, 1-5 objects, 5-9 frames; only 5 videos
+# for 8 ranks, so three ranks own nothing and must still take part in both collectives.
+_YTVOS_VIDEOS = [(7, 480, 854, 1), (5, 720, 1280, 3), (9, 480, 854, 5), (6, 720, 1280, 2), (8, 480, 854, 4)]
+
+
+def _ytvos_labels(v):
+    n, H, W, no = _YTVOS_VIDEOS[v]
+    g = torch.Generator().manual_seed(900 + v)
+    return torch.randint(0, no + 1, (n, H // 8, W // 8), generator=g, dtype=torch.uint8)   # (1/8 size: the test moves ~1 MB)
+
+
+def _eight_rank_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from rmnet_amd import dist as rd
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    rd.init_from_env(backend='gloo')
+    costs = [n * no for n, _, _, no in _YTVOS_VIDEOS]
+    mine = rd.my_videos(costs, rank, world)
+    res = {v: _ytvos_labels(v) for v in mine}
+    rd.barrier()
+    out = rd.gather_label_maps(res, len(costs))
+    n_owners = rd.sum_over_ranks(1.0 if mine else 0.0)
+    slowest = rd.max_over_ranks(float(sum(costs[v] for v in mine)))
+    if rank == 0:
+        q.put((mine, {v: t.numpy().copy() for v, t in out.items()}, n_owners, slowest))
+    else:
+        assert out == {}
+        q.put((mine, None, n_owners, slowest))
+    dist.destroy_process_group()
+
+
+def test_eight_rank_sharding_and_gather_with_idle_ranks_gloo():
+    """BASELINE configs[3] without the hardware: 8 gloo ranks, 5 videos of mixed resolution / object count / length.
+    assign_videos gives every video to exactly one rank (three ranks stay idle), every rank joins the header
+    all_gather and the padded gather, rank 0 gets every label map bit for bit, and the reductions agree on all ranks."""
+    import torch.multiprocessing as mp
+    from rmnet_amd.dist import assign_videos
+    world = 8
+    costs = [n * no for n, _, _, no in _YTVOS_VIDEOS]
+    owner = assign_videos(costs, world)
+    assert sorted(owner) == sorted(set(owner)) and len(set(owner)) == 5      # 5 videos -> 5 distinct ranks
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eight_rank_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    seen = sorted(v for mine, _, _, _ in got for v in mine)
+    assert seen == [0, 1, 2, 3, 4]
+    assert sum(1 for mine, _, _, _ in got if not mine) == 3                  # idle ranks took part and returned
+    maps = [m for _, m, _, _ in got if m is not None]
+    assert len(maps) == 1 and sorted(maps[0]) == [0, 1, 2, 3, 4]
+    for v in range(5):
+        assert np.array_equal(maps[0][v], _ytvos_labels(v).numpy())
+    assert all(n == 5.0 for _, _, n, _ in got)
+    assert len({s for _, _, _, s in got}) == 1 and got[0][3] == float(max(costs))

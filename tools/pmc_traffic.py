@@ -4,10 +4,13 @@ file bench.py reads (profiles/bk_main_hbm_traffic.json, stamped with the kernel 
 
     python tools/pmc_traffic.py gpurun_out/pmc [--write-profile]
 
-Units: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB.  Calibration for THIS kernel's access pattern
-(16-byte-per-lane fragment loads): round 1 measured FETCH_SIZE 21467.9 KB against 21.5 MB of known input
-bytes on a dense single-object read -> factor 1.0 (the x2 correction MI355X_MICROARCH.md gives for wide
-streaming reads does not apply to this pattern); WRITE_SIZE 30069 KB vs 30.7 MB of partials -> factor 1.0."""
+Units: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB.  Calibration (round 3, tools/pmc_calib.sh, raw numbers in
+profiles/r03_power_ceiling.md): on a launch that fetches every bank byte exactly once bk_main's FETCH_SIZE reads
+10,962 KB against 20.43 MB of known bytes, and a 1 GiB device copy reads 524,300 KB -- the 1/2 rule of
+MI355X_MICROARCH.md holds for this kernel's 16-byte-per-lane loads -> FETCH_SIZE x 2; WRITE_SIZE 6,553.6 KB against
+6,553.5 KB of partials (copy: 1,048,576 KB per GiB) -> x 1.  (Rounds 1-2 used x 1 for both: their single-object
+"calibration" launch fetched every tile from two XCDs.)"""
+FETCH_FACTOR, WRITE_FACTOR = 2.0, 1.0
 import csv
 import json
 import os
@@ -48,7 +51,8 @@ def main():
                 'command': 'tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE (then WRITE_SIZE, separate pass) --kernel-trace -- '
                            'python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extras (8 object-frames per launch)',
                 'fetch_size_kb_per_launch': round(fetch['bk_main'][0], 1), 'write_size_kb_per_launch': round(write['bk_main'][0], 1),
-                'hbm_bytes_per_launch': int(1024 * (fetch['bk_main'][0] + write['bk_main'][0])),
+                'hbm_bytes_per_launch': int(1024 * (FETCH_FACTOR * fetch['bk_main'][0] + WRITE_FACTOR * write['bk_main'][0])),
+                'fetch_factor': FETCH_FACTOR, 'write_factor': WRITE_FACTOR,
                 'algorithmic_bytes_per_launch': abytes,
                 'calibration': __doc__.split('Units:')[1].strip(),
                 'other_kernels_same_run': {k: {'fetch_size_kb_per_launch': round(fetch.get(k, (0, 0))[0], 1),
