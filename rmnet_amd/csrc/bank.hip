@@ -43,6 +43,8 @@
 //             normalises and scatters the read-out to the query cells.  No combine kernel, no second pass
 //             over the partials by another launch.
 // bk_colsum : finishes a slot's column sums of the values (fixed summation order: reads are repeatable).
+#include <type_traits>
+
 #include "common.h"
 
 namespace rmnet {
@@ -311,6 +313,9 @@ constexpr int kRThreads = 64 * (kProducers + kConsumers);  // 768 = 12 waves = 3
                        //                             256 no static part (q_val half / masked cells), 1024 publish + ticket only (nobody merges)
 #ifndef BK_TAIL
 #define BK_TAIL 0      // experiments only: 1 no segment epilogue (accumulators kept alive, nothing stored)
+#endif
+#ifndef BK_STATIC_ABL
+#define BK_STATIC_ABL 0   // experiments only: 1 static part without its stores, 2 without its q_val loads
 #endif
 #ifndef BK_PRIO
 #define BK_PRIO 2
@@ -771,10 +776,12 @@ __device__ inline float wave_sum_f(float v) {
 // drained by a few workgroups that get no chunk (the plan sets them aside, scaled to the launch) while the others
 // compute, and by every workgroup that has finished its segments -- among them the early arrivers of a pair, while
 // the pair's last arriver merges.
-constexpr int kStaticUnits = 9;                                 // 16-byte units per thread and queue item (at most), all in flight at once
-constexpr int kStaticRows = 128;                                // (object, channel) rows per queue item, at most
+#ifndef BK_STATIC_ROWS
+#define BK_STATIC_ROWS 2
+#endif
+constexpr int kStaticRowsPerTicket = BK_STATIC_ROWS;            // (object, channel) rows a wave takes per ticket
 #ifndef BK_STATIC_BPUS
-#define BK_STATIC_BPUS 50.0e3f
+#define BK_STATIC_BPUS 35.0e3f
 #endif
 constexpr float kStaticBytesPerUs = BK_STATIC_BPUS;             // what one streaming workgroup moves (sizing of the set-aside)
 constexpr float kTileUs = 1.75f, kLaunchUs = 12.0f;             // tile step / fixed part of a compute workgroup (same estimate)
@@ -801,7 +808,6 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   __shared__ int o_njt[kMaxObj], o_m[kMaxObj], o_nqt[kMaxObj], o_cb[kMaxObj], o_sb[kMaxObj];
   __shared__ int o_rect[kMaxObj][4];
   __shared__ int plan_n, plan_c, sflag;
-  __shared__ float smean[kStaticRows];
   char* Kl_ = lds;                                 // [ring slot][plane][8 KB]
   char* Pl_ = lds + 8 * kKbuf;                     // [buf][ntile][plane][lane*16]
   float* Al = reinterpret_cast<float*>(Pl_ + 2 * kPbuf);
@@ -1211,66 +1217,56 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   };   // compute()
   if ((int)blockIdx.x < nchunks) {
     compute();
-#if BK_CLK
-    if (tid == 0) {   // experiments: shader cycles vs constant-rate (100 MHz) clock of this workgroup's compute part
-      long long* cb = reinterpret_cast<long long*>(a.ws_plan + (size_t)(a.obj0 + a.nobj) * kPlanInts + 16) + 2 * blockIdx.x;
-      cb[0] = (long long)__builtin_readcyclecounter() - t_entry;
-      cb[1] = (long long)__builtin_amdgcn_s_memrealtime() - t_real;
-    }
-#endif
   }
+#if BK_CLK
+  int clk_tickets = 0;
+  if (tid == 0) {   // experiments: shader cycles vs constant-rate (100 MHz) clock of this workgroup's compute part
+    long long* cb = reinterpret_cast<long long*>(a.ws_plan + (size_t)(a.obj0 + a.nobj) * kPlanInts + 16) + 4 * blockIdx.x;
+    cb[0] = (long long)__builtin_readcyclecounter() - t_entry;
+    cb[1] = (long long)__builtin_amdgcn_s_memrealtime() - t_real;
+  }
+#endif
 
   // =========================================== static part: drain the queue ===========================================
-  // A queue item = `rpc` consecutive (object, channel) rows of ONE object (rpc is a power of two <= 128, so items never
-  // straddle objects).  The box test is per CELL, the same for every channel row: it is evaluated once per object into
-  // an LDS byte per unit (bits 0-3: cell inside the query box, bits 4-7: cell gets the mean), so the per-unit work is a
-  // load, four selects and one or two stores -- a stream, not arithmetic.
+  // A workgroup pulls tickets of 12 x kStaticRowsPerTicket (object, channel) rows (one atomic per ticket: with a
+  // ticket per WAVE the 3,072 waves of a launch saturated the queue word -- ~88 atomics per us -- and a pull took
+  // 35 us); inside a ticket every wave walks its own rows, no barrier.  A row is hw cells = hwv units of 16 bytes (4 bytes
+  // when the rows cannot be moved 16 bytes at a time); lane l handles units l, l + 64, ...  The box test is per CELL,
+  // identical for all 512 rows of an object: the wave keeps a byte per unit of its current object in its own LDS patch
+  // (bits 0-3: cell inside the query box, bits 4-7: cell gets the mean) and a 16-entry table turns the low nibble into a
+  // 0/1 float4.  Everything goes through buffer instructions whose offset is pushed out of range for the lanes that must
+  // not store: STRAIGHT-LINE code.  (With branches around the stores hipcc could not count the loads in flight and put
+  // s_waitcnt vmcnt(0) in front of every unit, i.e. every unit waited for the previous unit's stores to land: 12-14 us
+  // per ticket whatever else was tried.)
   if (!(BK_ABLATE & 256)) {
     const bool vec4 = (hw & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.qv) | reinterpret_cast<uintptr_t>(a.out)) & 15) == 0;
-    const int hwv = vec4 ? hw >> 2 : hw, nvec = vec4 ? 4 : 1;
-    constexpr int kB = kStaticUnits;                   // units per thread and item = loads in flight per buffer
-    int rpc = 1;
-    while (rpc < kStaticRows && rpc * 2 * hwv <= kB * kRThreads) rpc *= 2;
-    const int nrow_total = ng * kDo, nitems = nrow_total / rpc;              // (kDo is a multiple of rpc)
-    const int nunits = rpc * hwv;                                            // <= kB * kRThreads unless one row alone is longer
+    constexpr int kMaskUnits = 4096;                   // units of a wave's mask patch (longer rows are walked in pieces)
+    constexpr int kUI = 7;                             // units per lane and step (7 x 64 = 448 >= the 405 units of a 480p row)
+    constexpr int kMixMax = 512;                       // mixed units (some cells of the unit get the mean, some do not) per piece
+    constexpr int kOOB = 0x40000000;                   // a byte offset no row reaches: the buffer unit drops the access
+    constexpr int kRowsPerTicket = kStaticRowsPerTicket * (kProducers + kConsumers);
+    const int nrow_total = ng * kDo;
+    const int ntickets = (nrow_total + kRowsPerTicket - 1) / kRowsPerTicket;
     const float* __restrict__ qv0 = a.qv + (size_t)a.obj0 * kDo * hw;      // rows (og, d) of the launch, contiguous
     float* __restrict__ out0 = a.out + (size_t)a.obj0 * 2 * kDo * hw;
     const float inv_cells = 1.0f / ((float)T_ * (float)hw);
-    const int step_row = kRThreads / hwv, step_cu = kRThreads - step_row * hwv;
-    unsigned char* umask = reinterpret_cast<unsigned char*>(Kl_);          // [2][hwv] (the K ring is idle here)
-    float* smean2 = reinterpret_cast<float*>(Kl_ + 2 * ((hwv + 15) & ~15));  // [2][kStaticRows]
-
-    auto issue = [&](int it, f32x4 (&dst)[kB]) {       // the first kB units per thread of item `it` (unconditional loads)
-      const float* __restrict__ src = qv0 + (size_t)it * rpc * hw;
-#pragma unroll
-      for (int k = 0; k < kB; ++k) {
-        const int u = min(k * kRThreads + tid, nunits - 1);
-        dst[k] = vec4 ? reinterpret_cast<const f32x4*>(src)[u] : f32x4{src[u], 0.f, 0.f, 0.f};
-      }
+    unsigned char* umask = reinterpret_cast<unsigned char*>(Kl_) + wave * kMaskUnits;      // this wave's patch
+    f32x4* lut = reinterpret_cast<f32x4*>(Kl_ + (kProducers + kConsumers) * kMaskUnits);   // [16] nibble -> 0/1 float4
+    unsigned short* mixlist = reinterpret_cast<unsigned short*>(Pl_) + wave * kMixMax;     // this wave's mixed units: unit | nibble << 12
+    int nmix = 0, mask_obj = -1, mask_piece = -1;      // what this wave's patch currently holds
+    auto row_rsrc = [&](const float* base) {           // descriptor of one row (wave-uniform base, hw floats)
+      const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(base));
+      const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(base) >> 32));
+      return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((uintptr_t)bhi << 32) | blo), 0, hw * 4, 0x00020000);
     };
-    auto means = [&](int it, int buf) {                // column sums of the item's rows -> smean2[buf]: one wave per row, lanes
-      const int r0 = it * rpc, og_ = r0 / kDo;         // over the frames, fixed order; two rows per step and wave
-      const float* __restrict__ cs0 = b.colsum + ((size_t)(a.obj0 + og_) * b.Tcap) * kDo + (r0 - og_ * kDo);
-      for (int ra = wave; ra < rpc; ra += 2 * (kProducers + kConsumers)) {
-        const int rb = ra + kProducers + kConsumers;
-        float pa = 0.0f, pb = 0.0f;
-        for (int t = lane0; t < T_; t += RMNET_WAVE) {
-          pa += cs0[(size_t)t * kDo + ra];
-          if (rb < rpc) pb += cs0[(size_t)t * kDo + rb];
-        }
-        pa = wave_sum_f(pa);
-        pb = wave_sum_f(pb);
-        if (lane0 == 0) {
-          smean2[buf * kStaticRows + ra] = pa * inv_cells;
-          if (rb < rpc) smean2[buf * kStaticRows + rb] = pb * inv_cells;
-        }
-      }
-    };
-    auto mask_build = [&](int og, int buf) {
+    auto build_masks = [&](int og, int p0, int pn, int nvec) {
       const Rect rc{o_rect[og][0], o_rect[og][1], o_rect[og][2], o_rect[og][3]};
       const bool nomem = o_njt[og] == 0;
-      for (int cu = tid; cu < hwv; cu += kRThreads) {
-        int cell = cu * nvec, cy = cell / b.w, cx = cell - cy * b.w;
+      const unsigned full = nvec == 4 ? 15u : 1u;
+      nmix = 0;
+      for (int cb = 0; cb < pn; cb += RMNET_WAVE) {
+        const int cu = cb + lane0;
+        int cell = (p0 + cu) * nvec, cy = cell / b.w, cx = cell - cy * b.w;
         unsigned m = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1279,86 +1275,161 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
           m |= ((!inside || nomem) && e < nvec ? 1u : 0u) << (4 + e);
           if (++cx == b.w) { cx = 0; ++cy; }
         }
-        umask[buf * hwv + cu] = (unsigned char)m;
-      }
-    };
-    auto write_unit = [&](int it, int row, int cu, f32x4 x, int sbuf, int mbuf) {
-      const int r0 = it * rpc, og = r0 / kDo;
-      float* __restrict__ qdst = out0 + ((size_t)og * kDo + kDo + r0) * hw;   // out[og][kDo + d]: row index og * 2 kDo + kDo + d
-      float* __restrict__ mdst = out0 + ((size_t)og * kDo + r0) * hw;         // out[og][d]
-      const unsigned m = umask[mbuf * hwv + cu];
-      const float mu = smean2[sbuf * kStaticRows + row];
-      const int off = row * hw + cu * nvec;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) x[e] = (m >> e & 1u) ? x[e] : x[e] * 0.0f;   // x * 0: NaN / Inf propagate as in the reference
-      if (vec4) {
-        *reinterpret_cast<f32x4*>(qdst + off) = x;
-        if ((m >> 4) == 15u) *reinterpret_cast<f32x4*>(mdst + off) = f32x4{mu, mu, mu, mu};
-        else if (m >> 4) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (m >> (4 + e) & 1u) mdst[off + e] = mu;
+        const bool mixed = cu < pn && (m >> 4) != 0u && (m >> 4) != full;   // handled by the per-row list pass
+        const unsigned long long bal = __ballot(mixed);
+        if (mixed) {
+          const int at = nmix + __popcll(bal & ((1ull << lane0) - 1ull));
+          if (at < kMixMax) mixlist[at] = (unsigned short)(cu | (m >> 4) << 12);
         }
-      } else {
-        qdst[off] = x[0];
-        if (m >> 4 & 1u) mdst[off] = mu;
+        nmix += __popcll(bal);
+        if (cu < pn) umask[cu] = (unsigned char)m;
+      }
+      __builtin_amdgcn_wave_barrier();
+    };
+    // One step = kUI units per lane of one row.  VEC4: 16-byte units, else 4-byte units (same code, narrower accesses).
+    auto run_ticket = [&](auto vec_tag, int ticket) {
+      constexpr bool V4 = decltype(vec_tag)::value;
+      constexpr int nvec = V4 ? 4 : 1, ub_bytes = V4 ? 16 : 4;
+      const int hwv = V4 ? hw >> 2 : hw;
+      const int row0w = ticket * kRowsPerTicket + wave * kStaticRowsPerTicket;
+      // column sums of this wave's rows (lanes over the frames, fixed order): requested first, used row by row
+      float mus[kStaticRowsPerTicket];
+#pragma unroll
+      for (int rr = 0; rr < kStaticRowsPerTicket; ++rr) {
+        const int row = min(row0w + rr, nrow_total - 1), og = row / kDo, d = row - og * kDo;
+        const float* __restrict__ cs = b.colsum + ((size_t)(a.obj0 + og) * b.Tcap) * kDo + d;
+        mus[rr] = 0.0f;
+        for (int t = lane0; t < T_; t += RMNET_WAVE) mus[rr] += cs[(size_t)t * kDo];
+      }
+      // ... and so is the first step of every row: ALL of the ticket's loads are in flight before the first store
+      // (a row-by-row walk pays one full memory latency per row: measured 5 us per row and wave)
+      u32x4 x0[kStaticRowsPerTicket][kUI];
+#pragma unroll
+      for (int rr = 0; rr < kStaticRowsPerTicket; ++rr) {
+        const int row = min(row0w + rr, nrow_total - 1);
+        const __amdgpu_buffer_rsrc_t rs_src = row_rsrc(qv0 + (size_t)row * hw);
+#pragma unroll
+        for (int i = 0; i < kUI; ++i) {
+          const int off = (i * RMNET_WAVE + lane0) * ub_bytes;
+          if (V4) x0[rr][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, off, 0, 0);
+          else x0[rr][i] = u32x4{__builtin_amdgcn_raw_buffer_load_b32(rs_src, off, 0, 0), 0u, 0u, 0u};
+        }
+      }
+#pragma unroll
+      for (int rr = 0; rr < kStaticRowsPerTicket; ++rr) {
+        const int row = row0w + rr;
+        if (row >= nrow_total) break;
+        const int og = row / kDo, d = row - og * kDo;
+        const float mu = wave_sum_f(mus[rr]) * inv_cells;     // the row's mean of m_val over ALL T*h*w cells
+        const u32x4 mu4 = {__float_as_uint(mu), __float_as_uint(mu), __float_as_uint(mu), __float_as_uint(mu)};
+        const __amdgpu_buffer_rsrc_t rs_src = row_rsrc(qv0 + (size_t)row * hw);
+        const __amdgpu_buffer_rsrc_t rs_q = row_rsrc(out0 + ((size_t)og * 2 * kDo + kDo + d) * hw);   // out[og][kDo + d]
+        const __amdgpu_buffer_rsrc_t rs_m = row_rsrc(out0 + ((size_t)og * 2 * kDo + d) * hw);         // out[og][d]
+        for (int piece = 0; piece * kMaskUnits < hwv; ++piece) {
+          const int p0 = piece * kMaskUnits, pn = min(hwv - p0, kMaskUnits);
+          if (og != mask_obj || piece != mask_piece) {
+            build_masks(og, p0, pn, nvec);
+            mask_obj = og; mask_piece = piece;
+          }
+          for (int ub = 0; ub < pn; ub += kUI * RMNET_WAVE) {
+            u32x4 x[kUI];
+            if (ub == 0 && piece == 0) {
+#pragma unroll
+              for (int i = 0; i < kUI; ++i) x[i] = x0[rr][i];
+            } else {                                   // (rows longer than one step: later steps are loaded here)
+#pragma unroll
+              for (int i = 0; i < kUI; ++i) {          // (a unit past the row: out of range, returns 0)
+                const int off = (p0 + ub + i * RMNET_WAVE + lane0) * ub_bytes;
+                if (V4) x[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, off, 0, 0);
+                else x[i] = u32x4{__builtin_amdgcn_raw_buffer_load_b32(rs_src, off, 0, 0), 0u, 0u, 0u};
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < kUI; ++i) {
+              const int ul = ub + i * RMNET_WAVE + lane0;                    // unit inside the piece
+              const int off = (p0 + ul) * ub_bytes;
+              const unsigned m = umask[min(ul, kMaskUnits - 1)];             // (past the piece: whatever -- the stores are dropped)
+              const f32x4 keep = lut[m & 15u];
+              f32x4 y = __builtin_bit_cast(f32x4, x[i]);
+#pragma unroll
+              for (int e = 0; e < nvec; ++e) y[e] *= keep[e];              // x * 1 = x, x * 0 = +-0 / NaN: the reference's q_val * box (:358)
+              const int qoff = ul < pn ? off : kOOB;
+              const int moff = (ul < pn && (m >> 4) == (V4 ? 15u : 1u)) ? off : kOOB;   // (mixed units: the list pass)
+#if !(BK_STATIC_ABL & 1)
+              if (V4) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rs_q, qoff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(mu4, rs_m, moff, 0, 0);
+              } else {
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[0]), rs_q, qoff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mu), rs_m, moff, 0, 0);
+              }
+#else
+              asm volatile("" :: "v"(y), "v"(qoff), "v"(moff));
+#endif
+            }
+          }
+          // ---- the few units with cells on both sides of the box edge: one lane per unit, per-cell stores
+          if (V4) {
+            if (nmix > kMixMax) {                                          // (cannot happen on RMNet's grids: walk all units)
+              for (int cu = lane0; cu < pn; cu += RMNET_WAVE) {
+                const unsigned nib = umask[cu] >> 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mu), rs_m,
+                                                        (nib != 15u && (nib >> e & 1u)) ? (p0 + cu) * 16 + e * 4 : kOOB, 0, 0);
+              }
+            } else {
+              for (int k = lane0; k < nmix; k += RMNET_WAVE) {
+                const unsigned ent = mixlist[k];
+                const int off = (p0 + (int)(ent & 0xfffu)) * 16;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mu), rs_m, (ent >> (12 + e) & 1u) ? off + e * 4 : kOOB, 0, 0);
+              }
+            }
+          }
+        }
       }
     };
-
-    __syncthreads();                                   // (the compute part's LDS traffic is over; sflag is free)
+    // Inside the loop only LDS (the ticket word) crosses the barrier: a plain __syncthreads() is also a memory fence and
+    // waits for every outstanding global store of the wave, so the loop uses the bare barrier behind an LDS-only wait.
+    auto lds_barrier = [&]() {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    };
+    __syncthreads();                                   // (the compute part's LDS traffic is over)
+    if (tid < 16) lut[tid] = f32x4{(tid & 1) ? 1.f : 0.f, (tid & 2) ? 1.f : 0.f, (tid & 4) ? 1.f : 0.f, (tid & 8) ? 1.f : 0.f};
     if (tid == 0) sflag = __hip_atomic_fetch_add(q_head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    int item = sld(sflag);
-    int sbuf = 0, mbuf = 0, og = 0;
-    f32x4 v[kB];                                       // ONE set of load registers: an item's loads are issued right after the
-    int t_next = 0;                                    // previous item's stores (a spill here would put a vmcnt(0) drain --
-                                                       // scratch is vector memory -- behind every unit: measured 40 us per item)
-    if (item < nitems) {
-      og = item * rpc / kDo;
-      issue(item, v);
+    int ticket = sld(sflag);
+#if BK_CLK
+    int clk_tickets_ = 0;
+#endif
+    while (ticket < ntickets) {
+      lds_barrier();                                   // (everybody has read sflag)
+      int t_next = 0;                                  // the next ticket flies while this one is worked on
       if (tid == 0) t_next = __hip_atomic_fetch_add(q_head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      mask_build(og, mbuf);
-      means(item, sbuf);
-    }
-    __syncthreads();                                   // (nobody reads the first sflag any more)
-    if (tid == 0) sflag = t_next;
-    __syncthreads();
-    int next = sld(sflag);
-    while (item < nitems) {
-      // ---- write item `item` (its loads were issued one step ago)
-      int row = tid / hwv, cu = tid - row * hwv;       // this thread's units: u = tid, tid + kRThreads, ...; no division per unit
-#pragma unroll
-      for (int k = 0; k < kB; ++k) {
-        if (k * kRThreads + tid < nunits) write_unit(item, row, cu, v[k], sbuf, mbuf);
-        row += step_row; cu += step_cu;
-        if (cu >= hwv) { cu -= hwv; ++row; }
-      }
-      for (int u = kB * kRThreads + tid; u < nunits; u += kRThreads) {     // (only when one row alone exceeds an item: huge grids)
-        const float* __restrict__ src = qv0 + (size_t)item * rpc * hw;
-        write_unit(item, row, cu, vec4 ? reinterpret_cast<const f32x4*>(src)[u] : f32x4{src[u], 0.f, 0.f, 0.f}, sbuf, mbuf);
-        row += step_row; cu += step_cu;
-        if (cu >= hwv) { cu -= hwv; ++row; }
-      }
-      // ---- request the next item: loads, column sums, masks of a new object, the ticket after it
-      const bool more = next < nitems;
-      const int og_next = more ? next * rpc / kDo : og;
-      const int mbuf_next = og_next == og ? mbuf : mbuf ^ 1;
-      if (more) {
-        issue(next, v);
-        if (tid == 0) t_next = __hip_atomic_fetch_add(q_head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (og_next != og) mask_build(og_next, mbuf_next);
-        means(next, sbuf ^ 1);
-      }
+      if (vec4) run_ticket(std::true_type{}, ticket);
+      else run_ticket(std::false_type{}, ticket);
       if (tid == 0) sflag = t_next;
-      __syncthreads();                                 // next item's means / masks / the following ticket are visible
-      item = next;
-      next = sld(sflag);
-      sbuf ^= 1;
-      mbuf = mbuf_next;
-      og = og_next;
-      __syncthreads();                                 // (sflag may be rewritten)
+      lds_barrier();
+      ticket = sld(sflag);
+#if BK_CLK
+      ++clk_tickets_;
+#endif
     }
+#if BK_CLK
+    clk_tickets = clk_tickets_;
+#endif
   }
+#if BK_CLK
+  if (tid == 0) {   // experiments: static tickets this workgroup served, and when it left (100 MHz ticks since entry)
+    long long* cb = reinterpret_cast<long long*>(a.ws_plan + (size_t)(a.obj0 + a.nobj) * kPlanInts + 16) + 4 * blockIdx.x;
+    cb[2] = clk_tickets;
+    cb[3] = (long long)__builtin_amdgcn_s_memrealtime() - t_real;
+  }
+#endif
   // ---- leave: the last workgroup out zeroes the queue words for the next read (every workgroup comes through here)
   if (tid == 0) {
     const int gone = __hip_atomic_fetch_add(q_exit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -1,6 +1,7 @@
 # -*- coding: utf-8 -*-
-"""Shader clock under bk_main (needs a library built with -DBK_CLK=1): per workgroup, elapsed shader
-cycles (s_memtime) vs elapsed constant-rate ticks (s_memrealtime, 100 MHz).
+"""Shader clock and static-queue accounting of bk_main (needs a library built with -DBK_CLK=1): per workgroup,
+elapsed shader cycles (s_memtime) vs elapsed constant-rate ticks (s_memrealtime, 100 MHz) of its compute part, the
+number of static-queue tickets it served and when it left the kernel.
     python tools/bk_clk.py <no> <q_h> <q_w> <m_h> <m_w> [T]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,12 +27,17 @@ ws = torch.zeros(nb, dtype=torch.uint8, device=dev)
 for _ in range(20):
     bank.read(T, qk, qv, qr, ws=ws)
 torch.cuda.synchronize()
-tail = ws[nb - 8192 - 256:].cpu().numpy()
 # the stamps start 64 bytes after the plan records (which end somewhere inside the last 256-byte pad)
 plan_end = (no * 12 * 4)
-off = 256 - ((-plan_end) % 256 if plan_end % 256 else 0)
-raw = ws[nb - 8192 - ((plan_end + 255) // 256 * 256) + plan_end + 64:][:256 * 16].view(torch.int64).cpu().numpy().reshape(-1, 2)
-raw = raw[(raw[:, 1] > 0) & (raw[:, 0] > 0)]
-ghz = raw[:, 0] / (raw[:, 1] * 10.0)   # cycles per ns (100 MHz real-time ticks = 10 ns each)
-print('no=%d: %d workgroups stamped; shader cycles %.0f..%.0f, real us %.1f..%.1f, clock GHz mean %.3f min %.3f max %.3f'
-      % (no, len(raw), raw[:, 0].min(), raw[:, 0].max(), raw[:, 1].min() / 100.0, raw[:, 1].max() / 100.0, ghz.mean(), ghz.min(), ghz.max()))
+raw = ws[nb - 8192 - ((plan_end + 255) // 256 * 256) + plan_end + 64:][:256 * 32].view(torch.int64).cpu().numpy().reshape(-1, 4)
+comp = raw[(raw[:, 1] > 0) & (raw[:, 0] > 0)]
+ghz = comp[:, 0] / (comp[:, 1] * 10.0)   # cycles per ns (100 MHz real-time ticks = 10 ns each)
+print('no=%d: %d workgroups stamped; compute part: shader cycles %.0f..%.0f, real us %.1f..%.1f, clock GHz mean %.3f min %.3f max %.3f'
+      % (no, len(comp), comp[:, 0].min(), comp[:, 0].max(), comp[:, 1].min() / 100.0, comp[:, 1].max() / 100.0, ghz.mean(), ghz.min(), ghz.max()))
+tick, left = raw[:, 2], raw[:, 3] / 100.0
+early = comp[:, 1] / 100.0 < 0.5 * np.median(comp[:, 1] / 100.0)           # workgroups without a chunk: set aside for the static part
+print('static queue: %d tickets served in all; set-aside workgroups (%d): %s tickets each, left at %.1f..%.1f us; '
+      'the others: %d tickets in all after their compute part, left at %.1f..%.1f us'
+      % (tick.sum(), int(early.sum()), sorted(tick[(raw[:, 1] > 0)][early].tolist()), left[(raw[:, 1] > 0)][early].min() if early.any() else 0,
+         left[(raw[:, 1] > 0)][early].max() if early.any() else 0, int(tick[(raw[:, 1] > 0)][~early].sum()),
+         left[(raw[:, 1] > 0)][~early].min(), left[(raw[:, 1] > 0)][~early].max()))
