@@ -121,7 +121,7 @@ int rmnet_memory_read_f32(const float *m_key, const float *m_val, const float *q
                           void *workspace, size_t workspace_bytes, void *stream);
 
 /* Same call, with optional HIP events recorded on `stream` around the two kernels of the fast
- * path: ev_start before the read kernel, ev_mid after it, ev_end after the combine kernel of the exact-fp32
+ * path: ev_start at the very start of the call (before the staging pass), ev_mid after the read kernel, ev_end after the combine kernel of the exact-fp32
  * path (which returns at once when the split-fp16 bank kernel did the whole read)
  * (each a hipEvent_t as void*, any may be NULL).  bench.py uses this to time the dominant kernel
  * on the stream it actually runs on; it changes nothing else. */
@@ -157,6 +157,8 @@ int rmnet_memory_read_f32_ev(const float *m_key, const float *m_val, const float
  *       16-byte group written with such an element increments the int32 overflow word that lives at byte
  *       rmnet_bank_overflow_offset() of the bank; a caller that cannot rule such inputs out checks it (once per
  *       clip is enough) and re-runs with rmnet_memory_read_f32(..., RMNET_MR_EXACT_FP32).
+ *       The QUERY is split the same way after scaling by log2(e)/sqrt(128) * 2^6 (about 8.2): |q_key| beyond ~8e3 (or
+ *       NaN / Inf in q_key) saturates WITHOUT being counted -- the overflow word covers what is memorised only.
  *       rmnet_bank_area_offset(): byte offset of the int32 [no][Tcap] table of cells stored per slot (accounting).
  *       Tcap <= 2048.
  * ------------------------------------------------------------------------------------------- */

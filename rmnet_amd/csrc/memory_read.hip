@@ -814,6 +814,8 @@ int launch_memory_read(const MemReadArgs& m, hipStream_t st) {
     a.ws_ml = reinterpret_cast<float*>(static_cast<char*>(m.ws) + align256(nslots * kDo * kQT * 4));
     a.ws_plan = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.ws_ml) + align256(nslots * 2 * kQT * 4));
     char* bank = reinterpret_cast<char*>(a.ws_plan) + align256((size_t)m.no * kPlanInts * 4);
+    // (the optional timing events bracket the WHOLE call: staging pass included)
+    if (m.ev_start && hipEventRecord(m.ev_start, st) != hipSuccess) return RMNET_E_LAUNCH;
     if (via_bank) {
       const BankView b = bank_view(bank, m.no, m.T, m.h, m.w);
       // control block of the transient bank: the overflow word and the pairs' arrival tickets (the workspace is arbitrary memory)
@@ -827,7 +829,6 @@ int launch_memory_read(const MemReadArgs& m, hipStream_t st) {
     dim3 g1(a.slots, m.no);
     const int cch = comb_channels(m.no);
     dim3 g2((unsigned)(nqt_max + (regional ? (hw + kQT - 1) / kQT : 0)), kDo / cch, m.no);
-    if (m.ev_start && hipEventRecord(m.ev_start, st) != hipSuccess) return RMNET_E_LAUNCH;
     if (via_bank) {
       BankReadArgs r;
       r.bank = bank; r.no = m.no; r.Tcap = m.T; r.h = m.h; r.w = m.w; r.T = m.T;

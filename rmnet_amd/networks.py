@@ -359,14 +359,8 @@ def fuse_epilogues_(module, enable=True):
     if enable and any(isinstance(m, _Identity) for m in module.modules()):
         raise RuntimeError('fuse_epilogues() after fuse_for_inference(): the BatchNorms are already folded into '
                            'the convolutions -- use one or the other')
-    if enable and not getattr(module, '_fuse_hook', None):
-        # the (scale, shift) pairs and the 5-channel stem are SNAPSHOTS of the parameters: refresh them
-        # whenever a checkpoint is loaded afterwards, so that stale statistics can never be used
-        def _refresh(mod, incompatible):
-            if any(getattr(m, '_fused', False) for m in mod.modules()):
-                fuse_epilogues_(mod, True)
-        module._fuse_hook = module.register_load_state_dict_post_hook(_refresh)
-    for m in module.modules():
+    def snapshot(m):
+        """(Re)compute the (scale, shift) pairs / the stacked stem of ONE module from its current parameters."""
         if isinstance(m, _Bottleneck):
             for i, bn in ((1, m.bn1), (2, m.bn2), (3, m.bn3)):
                 sc, sh = _bn_scale_shift(bn)
@@ -376,13 +370,30 @@ def fuse_epilogues_(module, enable=True):
                 sc, sh = _bn_scale_shift(m.downsample[1])
                 put(m, '_sd', sc.contiguous())
                 put(m, '_bd', sh.contiguous())
-            m._fused = bool(enable)
         elif isinstance(m, (EncoderMemory, EncoderQuery)):
             sc, sh = _bn_scale_shift(m.bn1)
             put(m, '_s1', sc.contiguous())
             put(m, '_b1', sh.contiguous())
             if isinstance(m, EncoderMemory):
                 put(m, '_w5', torch.cat((m.conv1.weight, m.conv1_m.weight, m.conv1_o.weight), dim=1).contiguous())
+
+    def _refresh(mod, incompatible):
+        # load_state_dict() runs the post hooks of EVERY module it descends into, so a hook on each snapshot owner
+        # covers net.load_state_dict(...) as well as net.encoder_query.load_state_dict(...) or a single block's.
+        # (Editing a parameter in place is not observable: call fuse_epilogues() again after doing that.)
+        if getattr(mod, '_fused', False):
+            with torch.no_grad():
+                snapshot(mod)
+
+    for m in module.modules():
+        if isinstance(m, (_Bottleneck, EncoderMemory, EncoderQuery)):
+            snapshot(m)
+            handle = getattr(m, '_fuse_hook', None)
+            if enable and handle is None:
+                m._fuse_hook = m.register_load_state_dict_post_hook(_refresh)
+            elif not enable and handle is not None:
+                handle.remove()
+                m._fuse_hook = None
             m._fused = bool(enable)
         elif isinstance(m, (ResBlock, Refine)):
             m._fused = bool(enable)

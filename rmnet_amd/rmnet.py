@@ -333,12 +333,14 @@ class RMNet(nn.Module):
         float dtype), optical_flows [B,N,2,H,W] f32, n_objects [B,N] int -> est_masks [B,N,K,H,W]
         f32 on the GPU (the reference returns them on the host unless several GPUs are visible).
 
-        ``graph``: replay the frame step as ONE captured HIP graph instead of ~340 launches per frame.
-        None (default) = yes for clips of 8 frames or more on the split-fp16 bank; the first segmented frame always runs
-        eagerly (it warms MIOpen up and runs the fused-warp self-check), the graph is captured on the second.  The step has
-        no frame-dependent kernel argument -- the memory length lives in a device counter -- so one capture serves the
-        whole clip; only the copies into its static input buffers, the commit increment and the rare logit edits of
-        models/rmnet.py:436-448 happen outside it."""
+        ``graph=True``: replay the frame step as ONE captured HIP graph instead of ~340 launches per frame.
+        The first segmented frame always runs eagerly (it warms MIOpen up and runs the fused-warp self-check), the graph
+        is captured on the second.  The step has no frame-dependent kernel argument -- the memory length lives in a
+        device counter -- so one capture serves the whole clip; only the copies into its static input buffers, the commit
+        increment and the rare logit edits of models/rmnet.py:436-448 happen outside it.  Default OFF: measured on MI355X
+        (bench.py extras) the single 480p stream is bound by the batch-1 convolutions, not by launches -- replay gives
+        170 vs 168 frames/s with the memory pinned and LOSES on a free-running 67-frame clip (157 vs 164: the capture and
+        the four input copies per frame cost more than the launch gaps they remove)."""
         self._inference_only()
         dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         frames = frames.to(dev, non_blocking=True)
@@ -358,7 +360,7 @@ class RMNet(nn.Module):
         ctx = self._ClipContext(self, B, K, H, W, n_max, dev)
         bank = self.new_bank(ctx, sum(1 for j in commit if j <= N - 2) + 1, exact=_exact)
 
-        use_graph = (N >= 8 if graph is None else bool(graph)) and isinstance(bank, ops.MemoryBank)
+        use_graph = bool(graph) and isinstance(bank, ops.MemoryBank)
         replay = None
         for t in range(1, N):
             if use_graph and t >= 2:

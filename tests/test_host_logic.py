@@ -318,3 +318,24 @@ def test_eight_rank_sharding_and_gather_with_idle_ranks_gloo():
         assert np.array_equal(maps[0][v], _ytvos_labels(v).numpy())
     assert all(n == 5.0 for _, _, n, _ in got)
     assert len({s for _, _, _, s in got}) == 1 and got[0][3] == float(max(costs))
+
+
+def test_fused_epilogue_snapshots_follow_submodule_checkpoint_loads():
+    """Round-2 advisor finding: the (scale, shift) snapshots of fuse_epilogues() were refreshed only when the TOP module
+    loaded a checkpoint.  Loading into a sub-module must refresh them too, and fuse_epilogues(False) removes the hooks."""
+    from rmnet_amd import networks
+    from rmnet_amd.rmnet import RMNet
+    net = networks.procedural_init_(RMNet(None)).eval()
+    net.fuse_epilogues()
+    blk = [m for m in net.encoder_query.modules() if isinstance(m, networks._Bottleneck)][0]
+    before = blk._s1.clone()
+    sd = net.encoder_query.state_dict()
+    for k in list(sd):
+        if k.endswith('running_var'):
+            sd[k] = sd[k] * 4.0
+    net.encoder_query.load_state_dict(sd)
+    assert torch.allclose(blk._s1, before * 0.5, rtol=1e-4)            # 1 / sqrt(4 var): the snapshot followed the load
+    stem = net.encoder_query
+    assert torch.allclose(stem._s1, networks._bn_scale_shift(stem.bn1)[0])
+    net.fuse_epilogues(False)
+    assert all(getattr(m, '_fuse_hook', None) is None for m in net.modules())

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Raw evidence for DESIGN.md section 5 ("what bounds bk_main"): socket power under load, in-kernel shader clock,
 # the pure-MFMA ceiling on zero / random operands, and the energy-share table from ablated builds.
-# Needs build/variants/lib_{clk,a1,a2,a4,a8,a16}.so (tools/build_variant.sh) and tools/ubench/mfma_power.
+# Needs build/variants/lib_{clk,a1,a2,a4,a16,a256,a1024}.so (tools/build_variant.sh <name> -DBK_CLK=1 -DBK_ABLATE=<mask>)
+# and tools/ubench/mfma_power.
 # Output: gpurun_out/r03_power/raw.txt (copied, with the command lines, into profiles/r03_power_ceiling.md).
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 out=gpurun_out/r03_power
@@ -24,8 +25,9 @@ done
 echo
 echo "### energy shares: the bench-shaped launch (8 objects, 21x36 query box = 12 query tiles, 21x36 memory box x T=5 = 120 tiles)"
 echo "### with parts of bk_main compiled out (BK_ABLATE bit mask: 1 no V reloads, 2 no PV MFMAs, 4 no S/soft-max,"
-echo "### 8 no partial stores, 16 no K tile loads); every variant also carries -DBK_CLK=1 so the clock is read in the same launch"
-for v in clk a1 a2 a4 a8 a16 a3 a21; do
+echo "### 16 no K tile loads, 256 no static part (q_val half / masked cells), 1024 publish + ticket but nobody merges);"
+echo "### every variant also carries -DBK_CLK=1 so the clock is read in the same launch"
+for v in clk a1 a2 a4 a16 a256 a1024; do
   [ -f build/variants/lib_$v.so ] || continue
   echo "### \$ RMNET_HIP_LIB=build/variants/lib_$v.so python tools/chunk_bench.py $W ; ... bk_clk.py $W"
   RMNET_HIP_LIB=build/variants/lib_$v.so python tools/chunk_bench.py $W 2>&1 | tail -1
