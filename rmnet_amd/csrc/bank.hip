@@ -900,6 +900,10 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   __syncthreads();
   auto sld = [](const int& x) { return __builtin_amdgcn_readfirstlane(x); };   // LDS value -> SGPR
   const int nchunks = sld(plan_n), C = sld(plan_c);
+#if BK_CLK
+  long long* clk_rec = reinterpret_cast<long long*>(a.ws_plan + (size_t)(a.obj0 + a.nobj) * kPlanInts + 16) + 8 * blockIdx.x;
+  if (tid == 0) { clk_rec[4] = (long long)__builtin_amdgcn_s_memrealtime() - t_real; clk_rec[5] = 0; clk_rec[6] = 0; }   // plan done
+#endif
   if ((int)blockIdx.x < ng && tid == 0) {   // plan record of object blockIdx.x (tools / debugging only)
     const int og = blockIdx.x;
     int32_t* pr = a.ws_plan + (size_t)(a.obj0 + og) * kPlanInts;
@@ -974,10 +978,16 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
                                    // arithmetic of the loops below out of the segment loop (it then spills)
     f32x4 acc[kCDT][4];            // consumers: O of (64 channels x 64 queries)
     float m_seg = 0.0f, l_seg = 0.0f;   // producers: running reference (log2 domain) and sum of query 16 * wave + l15
+#if BK_CLK
+    if (tid == 0 && clk_rec[5] == 0) clk_rec[5] = (long long)__builtin_amdgcn_s_memrealtime() - t_real;   // first segment starts
+#endif
     if (producer)
       producer_loop(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, ln, t_entry, m_seg, l_seg);
     else
       consumer_loop(a, wk, Kl_, Pl_, Al, tpre, wave, ln, t_entry, acc);
+#if BK_CLK
+    if (tid == kRThreads - 1) clk_rec[6] = (long long)__builtin_amdgcn_s_memrealtime() - t_real;          // (last) tile loop over
+#endif
 
     // ================= segment epilogue (all 12 waves; every barrier below is reached by all of them) =================
 #if BK_TAIL == 1      // experiments: no epilogue at all (the accumulators are kept alive, nothing is stored)
@@ -1221,7 +1231,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
 #if BK_CLK
   int clk_tickets = 0;
   if (tid == 0) {   // experiments: shader cycles vs constant-rate (100 MHz) clock of this workgroup's compute part
-    long long* cb = reinterpret_cast<long long*>(a.ws_plan + (size_t)(a.obj0 + a.nobj) * kPlanInts + 16) + 4 * blockIdx.x;
+    long long* cb = reinterpret_cast<long long*>(a.ws_plan + (size_t)(a.obj0 + a.nobj) * kPlanInts + 16) + 8 * blockIdx.x;
     cb[0] = (long long)__builtin_readcyclecounter() - t_entry;
     cb[1] = (long long)__builtin_amdgcn_s_memrealtime() - t_real;
   }
@@ -1425,7 +1435,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   }
 #if BK_CLK
   if (tid == 0) {   // experiments: static tickets this workgroup served, and when it left (100 MHz ticks since entry)
-    long long* cb = reinterpret_cast<long long*>(a.ws_plan + (size_t)(a.obj0 + a.nobj) * kPlanInts + 16) + 4 * blockIdx.x;
+    long long* cb = reinterpret_cast<long long*>(a.ws_plan + (size_t)(a.obj0 + a.nobj) * kPlanInts + 16) + 8 * blockIdx.x;
     cb[2] = clk_tickets;
     cb[3] = (long long)__builtin_amdgcn_s_memrealtime() - t_real;
   }

@@ -882,7 +882,7 @@ size_t bank_read_ws_bytes(int no, int h, int w) {
   const size_t slots = bank_total_slots(no, h * w);
   return align256(slots * kDo * kQT * 4) + align256(slots * 2 * kQT * 4) + align256((size_t)no * kPlanInts * 4)
 #ifdef BK_CLK
-         + 8192
+         + 16384
 #endif
       ;
 }

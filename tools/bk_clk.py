@@ -29,7 +29,7 @@ for _ in range(20):
 torch.cuda.synchronize()
 # the stamps start 64 bytes after the plan records (which end somewhere inside the last 256-byte pad)
 plan_end = (no * 12 * 4)
-raw = ws[nb - 8192 - ((plan_end + 255) // 256 * 256) + plan_end + 64:][:256 * 32].view(torch.int64).cpu().numpy().reshape(-1, 4)
+raw = ws[nb - 16384 - ((plan_end + 255) // 256 * 256) + plan_end + 64:][:256 * 64].view(torch.int64).cpu().numpy().reshape(-1, 8)
 comp = raw[(raw[:, 1] > 0) & (raw[:, 0] > 0)]
 ghz = comp[:, 0] / (comp[:, 1] * 10.0)   # cycles per ns (100 MHz real-time ticks = 10 ns each)
 print('no=%d: %d workgroups stamped; compute part: shader cycles %.0f..%.0f, real us %.1f..%.1f, clock GHz mean %.3f min %.3f max %.3f'
@@ -41,3 +41,8 @@ print('static queue: %d tickets served in all; set-aside workgroups (%d): %s tic
       % (tick.sum(), int(early.sum()), sorted(tick[(raw[:, 1] > 0)][early].tolist()), left[(raw[:, 1] > 0)][early].min() if early.any() else 0,
          left[(raw[:, 1] > 0)][early].max() if early.any() else 0, int(tick[(raw[:, 1] > 0)][~early].sum()),
          left[(raw[:, 1] > 0)][~early].min(), left[(raw[:, 1] > 0)][~early].max()))
+c = raw[(raw[:, 1] > 0)][~early]
+us = lambda col: c[:, col] / 100.0
+print('compute workgroups, microseconds since kernel entry (median [min..max]): plan done %.1f [%.1f..%.1f]; first tile walk starts %.1f [%.1f..%.1f]; '
+      'last tile walk over %.1f [%.1f..%.1f]; epilogue (publish / merge / output) over %.1f [%.1f..%.1f]; left the kernel %.1f [%.1f..%.1f]'
+      % tuple(x for col in (4, 5, 6, 1, 3) for x in (np.median(us(col)), us(col).min(), us(col).max())))
