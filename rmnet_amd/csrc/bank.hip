@@ -270,7 +270,15 @@ __global__ __launch_bounds__(kDo) void bk_colsum(BankView b, int slot0, const in
   const int ntiles = (b.area[so] + kJT - 1) / kJT;
   const float* __restrict__ src = b.vpart + so * (size_t)(b.hwp / kJT) * kDo + d;
   float sum = 0.0f;
-  for (int u = 0; u < ntiles; ++u) sum += src[(size_t)u * kDo];
+  int u = 0;
+  for (; u + 8 <= ntiles; u += 8) {       // eight loads in flight, added in tile order (a dependent load per tile cost 15 us)
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = src[(size_t)(u + k) * kDo];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sum += v[k];
+  }
+  for (; u < ntiles; ++u) sum += src[(size_t)u * kDo];
   b.colsum[so * kDo + d] = sum;
 }
 
@@ -310,7 +318,9 @@ constexpr int kRThreads = 64 * (kProducers + kConsumers);  // 768 = 12 waves = 3
 #define BK_ABLATE 0    // experiments only, bit mask: 1 no V reloads, 2 no PV MFMAs, 4 no S/soft-max,
 #endif                 //                             8 no partial stores, 16 no K tile loads, 32 / 64 cheaper soft-max
                        //                             (changes the control flow: not a clean ablation), 128 a barrier every 2nd tile
-                       //                             256 no static part (q_val half / masked cells), 1024 publish + ticket only (nobody merges)
+                       //                             256 no static part (q_val half / masked cells), 1024 publish + ticket only (nobody merges),
+                       //                             2048 K / V tiles loaded on every SECOND tile only: the global-load traffic per flop of a
+                       //                             128-query workgroup, at this kernel's instruction stream (wrong results, timing only)
 #ifndef BK_TAIL
 #define BK_TAIL 0      // experiments only: 1 no segment epilogue (accumulators kept alive, nothing stored)
 #endif
@@ -605,7 +615,7 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
       BK_STAMP();   // soft-max done
       sp0 = s0; sp1 = s1;
       k_frags(f, kslot);                             // tile n+3: its LDS latency hides under the barrier
-      if (!(BK_ABLATE & 16)) {
+      if (!(BK_ABLATE & 16) && !((BK_ABLATE & 2048) && (n & 1))) {
         // K ring: tile n+4 (requested one iteration ago) -> slot n%4, whose last reader (tile n) passed
         // the barrier of iteration n-3; request tile n+5 (a clamped duplicate past the end: harmless)
         k_store(kr, (kslot + 1) & 3);
@@ -714,7 +724,7 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
       for (int it = 0; it < 4; ++it)
         acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[dt], bh[it], acc[dt][it], 0, 0, 0);
 #endif
-      if (!(BK_ABLATE & 1)) {   // this channel tile's fragments of the next tile, unconditionally
+      if (!(BK_ABLATE & 1) && !((BK_ABLATE & 2048) && (n & 1))) {   // this channel tile's fragments of the next tile, unconditionally
 #if BK_VNT
         vh[dt] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(nvh + dt * 1024));
         vl[dt] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(nvl + dt * 1024));

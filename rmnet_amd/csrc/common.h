@@ -164,7 +164,7 @@ constexpr int kPlanInts = 12;
 // stand for the price of starting another segment (query fragments, K ring fill, first soft-max, a
 // 128 KB partial), so a chunk that crosses pair boundaries gets that many tiles less.
 #ifndef RMNET_SEG_COST
-#define RMNET_SEG_COST 4
+#define RMNET_SEG_COST 6   // (4 until round 3: a segment now also ends with a publish / ticket / merge)
 #endif
 constexpr int kSegCost = RMNET_SEG_COST;
 struct BankChunks { int C, nfull, R, nrem, nch; };

@@ -26,6 +26,8 @@ for case, (no, T, h, w, seed) in enumerate([(2, 3, 6, 10, 5), (1, 5, 8, 8, 1), (
     mr = np.array([[rect() for _ in range(T)] for _ in range(no)], np.int32)
     mr[:, T - 1] = (0, w - 1, 0, h - 1)
     qr = np.array([(0, w - 1, 0, h - 1)] * no, np.int32)
+    if case % 2 == 1:                       # every second case: regional queries (static part + merge in one launch)
+        qr = np.array([rect() for _ in range(no)], np.int32)
     mk[:, :, T - 1, h - 1, w - 1] = qk[:, :, min(2, h - 1), min(3, w - 1)] * 9.0     # late spike
     want, _ = oracle.regional_memory_read(mk, mv, qk, qv, mr, qr)
     bank = ops.MemoryBank(no, T + 1, h, w, dev)

@@ -1396,3 +1396,50 @@ def test_forward_replays_one_hip_graph_for_the_whole_clip(oracle_mod):
     assert float((est_g - est_e).abs().max()) < 1e-3            # (MIOpen may pick another algorithm under capture)
     assert float((est_g - est_cpu).abs().max()) < 1e-3
     assert (est_g.argmax(2) == est_cpu.argmax(2)).float().mean() > 0.999
+
+
+def test_static_half_of_the_read_keeps_the_reference_semantics():
+    """The part of MemoryReader.forward that does not depend on the soft-max -- written by bk_main's work queue --:
+    (a) q_val x box is a MULTIPLICATION (models/rmnet.py:358): -0.0, Inf and NaN outside the box give -0.0 / NaN / NaN,
+    exactly like torch; (b) masked query cells read the mean of m_val over all T*h*w cells, for several objects with
+    different boxes in one launch, a grid whose rows cannot be moved 16 bytes at a time (5 x 7), and an object whose
+    memory boxes are all empty (every cell reads 0)."""
+    from rmnet_amd import ops
+    rng = np.random.RandomState(91)
+    for (no, T, h, w) in ((3, 2, 9, 12), (2, 3, 5, 7), (9, 2, 30, 54)):
+        mk, mv, qk, qv, mr, qr = _random_case(rng, no, T, h, w, regional=True)
+        qr[0] = (2, w - 3, 1, h - 2)
+        mr[no - 1, :] = (1, 0, 1, 0)                                    # nothing memorised inside any box
+        qv[0, 3, 0, 0] = np.inf
+        qv[0, 4, 0, 1] = np.nan
+        qv[0, 5, h - 1, w - 1] = -3.0
+        qv[0, 6, 1, 2] = np.nan                                         # inside the box of object 0: stays NaN as well
+        bank = _fill_bank(ops, mk, mv, mr)
+        got = bank.read(T, cu(qk), cu(qv), cu(qr)).cpu()
+        box = torch.zeros(no, 1, h, w)
+        for o in range(no):
+            x0, x1, y0, y1 = qr[o]
+            if x0 <= x1 and y0 <= y1:
+                box[o, 0, y0:y1 + 1, x0:x1 + 1] = 1
+        want_q = torch.from_numpy(qv) * box                             # the reference's expression
+        assert torch.equal(torch.isnan(got[:, 512:]), torch.isnan(want_q))
+        assert torch.equal(torch.nan_to_num(got[:, 512:], nan=7.0), torch.nan_to_num(want_q, nan=7.0))
+        assert torch.equal(torch.signbit(got[:, 512:]), torch.signbit(want_q))
+        mean = torch.from_numpy(oracle_masked_mean(mv, mr))             # [no, 512]
+        out_mem = got[:, :512]
+        outside = (box == 0).expand(no, 512, h, w)
+        np.testing.assert_allclose(out_mem[outside].numpy(), mean[:, :, None, None].expand(no, 512, h, w)[outside].numpy(),
+                                   atol=MR_ATOL, rtol=MR_RTOL)
+        assert float(out_mem[no - 1].abs().max()) == 0.0                # empty memory: soft-max over zeros of zeros
+
+
+def oracle_masked_mean(mv, mr):
+    """Mean over ALL T*h*w cells of the box-masked values (what a query cell with all-zero logits reads): numpy, fp64."""
+    no, C, T, h, w = mv.shape
+    m = np.zeros((no, 1, T, h, w))
+    for o in range(no):
+        for t in range(T):
+            x0, x1, y0, y1 = mr[o, t]
+            if x0 <= x1 and y0 <= y1:
+                m[o, 0, t, max(y0, 0):y1 + 1, max(x0, 0):x1 + 1] = 1
+    return ((mv.astype(np.float64) * m).sum(axis=(2, 3, 4)) / (T * h * w)).astype(np.float32)
