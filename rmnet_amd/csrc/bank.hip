@@ -339,6 +339,9 @@ constexpr int kRThreads = 64 * (kProducers + kConsumers);  // 768 = 12 waves = 3
 #ifndef BK_VNT
 #define BK_VNT 0       // experiments only: non-temporal V fragment loads
 #endif
+#ifndef BK_TERMS
+#define BK_TERMS 3     // experiments only: 1 = hi planes only (plain fp16 operands, fp32 accumulate)
+#endif
 #ifndef BK_CLK
 #define BK_CLK 0       // experiments only: per-workgroup shader-cycle / real-time stamps behind the plan records
 #endif
@@ -459,15 +462,19 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
     const size_t off = ((so0 + tt) * b.hwp + (size_t)ll * kJT) * kDe * sizeof(_Float16) + (size_t)pt * 16;
     kr[0] = *reinterpret_cast<const half8*>(b.kh + off);
     kr[1] = *reinterpret_cast<const half8*>(b.kh + off + 4096);
-    kr[2] = *reinterpret_cast<const half8*>(b.kl + off);
-    kr[3] = *reinterpret_cast<const half8*>(b.kl + off + 4096);
+    if (BK_TERMS == 3) {
+      kr[2] = *reinterpret_cast<const half8*>(b.kl + off);
+      kr[3] = *reinterpret_cast<const half8*>(b.kl + off + 4096);
+    }
   };
   auto k_store = [&](const half8 (&kr)[4], int slot) {
     char* d = Kl_ + slot * 2 * kKbuf + kdst;
     *reinterpret_cast<half8*>(d) = kr[0];
     *reinterpret_cast<half8*>(d + 4096) = kr[1];
-    *reinterpret_cast<half8*>(d + kKbuf) = kr[2];
-    *reinterpret_cast<half8*>(d + kKbuf + 4096) = kr[3];
+    if (BK_TERMS == 3) {
+      *reinterpret_cast<half8*>(d + kKbuf) = kr[2];
+      *reinterpret_cast<half8*>(d + kKbuf + 4096) = kr[3];
+    }
   };
   half8 kr[4];                     // K tile n+5 on its way to the ring (one iteration to land)
   Cursor ck;
@@ -498,14 +505,25 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
       const int sw = ((4 * ks + g) ^ l15) << 4;
       f.a0h[ks] = *reinterpret_cast<const half8*>(kb + l15 * 256 + sw);
       f.a1h[ks] = *reinterpret_cast<const half8*>(kb + (16 + l15) * 256 + sw);
-      f.a0l[ks] = *reinterpret_cast<const half8*>(kb + kKbuf + l15 * 256 + sw);
-      f.a1l[ks] = *reinterpret_cast<const half8*>(kb + kKbuf + (16 + l15) * 256 + sw);
+      if (BK_TERMS == 3) {
+        f.a0l[ks] = *reinterpret_cast<const half8*>(kb + kKbuf + l15 * 256 + sw);
+        f.a1l[ks] = *reinterpret_cast<const half8*>(kb + kKbuf + (16 + l15) * 256 + sw);
+      }
     }
   };
   // S = K^T Q of one tile (log2 domain).  Two accumulator chains (cells 0-15 / 16-31), the three
   // split terms summed inside the chain, small terms first; consecutive MFMAs alternate chains, which
   // is all the distance a dependent 16x16x32 MFMA needs.  Lane result: S[cell 4g + r (+16)][query l15].
   auto s_mfma = [&](const Frags& f, f32x4& s0, f32x4& s1) {
+    if (BK_TERMS == 1) {
+      s0 = s1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a0h[ks], qh[ks], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a1h[ks], qh[ks], s1, 0, 0, 0);
+      }
+      return;
+    }
     s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a0l[0], qh[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a1l[0], qh[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
@@ -560,12 +578,13 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
     for (int i = 0; i < 4; ++i) {
       const half2 h = {(_Float16)pv[2 * i], (_Float16)pv[2 * i + 1]};
       const unsigned hk = __builtin_bit_cast(unsigned, h);
-      unsigned lk;   // lo = fp16(p - hi): fp32 subtract and one rounding, straight into its half
+      unsigned lk = 0;   // lo = fp16(p - hi): fp32 subtract and one rounding, straight into its half
       // hipcc does not pad hazards around inline asm (cdna_hip_programming.md 5.7 item 2).  The inputs come
       // straight from v_exp_f32 / v_cvt_pk (a transcendental result needs one wait state before a VALU reads
       // it) and v_fma_mixhi reads the register v_fma_mixlo has just written with a destination half-select
       // (one more): without the s_nops one producer wave occasionally published a wrong lo plane -- errors of
       // ~5e-3 on 16 queries of one launch in thirty (tests/stress_race.py).
+      if (BK_TERMS == 3)
       asm("s_nop 0\n\t"
           "v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
           "s_nop 0\n\t"
@@ -577,7 +596,7 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
     }
     char* pb = Pl_ + pbuf * kPbuf + wave * 2048 + lane * 16;
     *reinterpret_cast<u32x4*>(pb) = ph;
-    *reinterpret_cast<u32x4*>(pb + 1024) = plo;
+    if (BK_TERMS == 3) *reinterpret_cast<u32x4*>(pb + 1024) = plo;
     if (g == 0) Al[pbuf * kQT + l15 * 4 + wave] = alpha;
   };
 
@@ -674,7 +693,7 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
 #pragma unroll
     for (int dt = 0; dt < kCDT; ++dt) {
       vh[dt] = *reinterpret_cast<const half8*>(b.vh + off + dt * 1024);
-      vl[dt] = *reinterpret_cast<const half8*>(b.vl + off + dt * 1024);
+      if (BK_TERMS == 3) vl[dt] = *reinterpret_cast<const half8*>(b.vl + off + dt * 1024);
     }
   }
 #pragma unroll
@@ -694,7 +713,7 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       bh[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + lane * 16);
-      bl[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + 1024 + lane * 16);
+      if (BK_TERMS == 3) bl[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + 1024 + lane * 16);
     }
     const int l1 = cv.seek(jt0 + n + 1);             // refill source: tile n+1 (clamped past the end)
     const size_t noff = v_tile(cv.tt, l1);
@@ -714,12 +733,14 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
 #pragma unroll
     for (int dt = 0; dt < kCDT; ++dt) {
 #if !(BK_ABLATE & 2)
+      if (BK_TERMS == 3) {
 #pragma unroll
-      for (int it = 0; it < 4; ++it)
-        acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[dt], bh[it], acc[dt][it], 0, 0, 0);
+        for (int it = 0; it < 4; ++it)
+          acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[dt], bh[it], acc[dt][it], 0, 0, 0);
 #pragma unroll
-      for (int it = 0; it < 4; ++it)
-        acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[dt], bl[it], acc[dt][it], 0, 0, 0);
+        for (int it = 0; it < 4; ++it)
+          acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[dt], bl[it], acc[dt][it], 0, 0, 0);
+      }
 #pragma unroll
       for (int it = 0; it < 4; ++it)
         acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[dt], bh[it], acc[dt][it], 0, 0, 0);
@@ -730,7 +751,7 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
         vl[dt] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(nvl + dt * 1024));
 #else
         vh[dt] = *reinterpret_cast<const half8*>(nvh + dt * 1024);
-        vl[dt] = *reinterpret_cast<const half8*>(nvl + dt * 1024);
+        if (BK_TERMS == 3) vl[dt] = *reinterpret_cast<const half8*>(nvl + dt * 1024);
 #endif
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE (the scheduler sinks them to the end)

@@ -27,7 +27,7 @@ echo "### energy shares: the bench-shaped launch (8 objects, 21x36 query box = 1
 echo "### with parts of bk_main compiled out (BK_ABLATE bit mask: 1 no V reloads, 2 no PV MFMAs, 4 no S/soft-max,"
 echo "### 16 no K tile loads, 256 no static part (q_val half / masked cells), 1024 publish + ticket but nobody merges);"
 echo "### every variant also carries -DBK_CLK=1 so the clock is read in the same launch"
-for v in clk a1 a2 a4 a16 a256 a1024; do
+for v in clk a1 a2 a4 a16 a17 a256 a1024; do
   [ -f build/variants/lib_$v.so ] || continue
   echo "### \$ RMNET_HIP_LIB=build/variants/lib_$v.so python tools/chunk_bench.py $W ; ... bk_clk.py $W"
   RMNET_HIP_LIB=build/variants/lib_$v.so python tools/chunk_bench.py $W 2>&1 | tail -1
