@@ -51,7 +51,7 @@ SIGNATURES = {
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i32p, c_f32p,
         c_f32p, c_i32p, ctypes.c_void_p]),
     'rmnet_bank_read_f32_at': (ctypes.c_int, [
-        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i32p, c_f32p,
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i32p, ctypes.c_int, c_f32p,
         c_f32p, c_i32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_void_p]),
     'rmnet_bank_read_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 3),
@@ -81,7 +81,7 @@ SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 

@@ -303,8 +303,8 @@ struct BArgs {
 constexpr int kKbuf = kJT * kDe * 2;                       // bytes of one K plane tile (8 KB)
 constexpr int kPbuf = 4 * 2 * 64 * 16;                     // P fragments of one tile [ntile][hi/lo][lane] x 16 B
 constexpr int kLdsBytes = 8 * kKbuf                        // K hi/lo x 4 ring slots
-                          + 2 * kPbuf                      // P double buffer
-                          + 2 * kQT * 4                    // alpha [buf][16 queries][4 query tiles]
+                          + 3 * kPbuf                      // P buffers (two in the split mode, three in the fp16 mode)
+                          + 3 * kQT * 4                    // alpha [buf][16 queries][4 query tiles]
                           + (kMaxT + 4) * 4                // tile prefix
                           + kMaxT * 4;                     // cells per frame
 constexpr int kProducers = 4;                              // waves 0-3
@@ -339,8 +339,8 @@ constexpr int kRThreads = 64 * (kProducers + kConsumers);  // 768 = 12 waves = 3
 #ifndef BK_VNT
 #define BK_VNT 0       // experiments only: non-temporal V fragment loads
 #endif
-#ifndef BK_TERMS
-#define BK_TERMS 3     // experiments only: 1 = hi planes only (plain fp16 operands, fp32 accumulate)
+#ifndef BK_F16_INTERLEAVE
+#define BK_F16_INTERLEAVE 6   // fp16 mode, producers: soft-max VALU instructions scheduled between two S MFMAs (0 = as the compiler likes)
 #endif
 #ifndef BK_CLK
 #define BK_CLK 0       // experiments only: per-workgroup shader-cycle / real-time stamps behind the plan records
@@ -462,19 +462,15 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
     const size_t off = ((so0 + tt) * b.hwp + (size_t)ll * kJT) * kDe * sizeof(_Float16) + (size_t)pt * 16;
     kr[0] = *reinterpret_cast<const half8*>(b.kh + off);
     kr[1] = *reinterpret_cast<const half8*>(b.kh + off + 4096);
-    if (BK_TERMS == 3) {
-      kr[2] = *reinterpret_cast<const half8*>(b.kl + off);
-      kr[3] = *reinterpret_cast<const half8*>(b.kl + off + 4096);
-    }
+    kr[2] = *reinterpret_cast<const half8*>(b.kl + off);
+    kr[3] = *reinterpret_cast<const half8*>(b.kl + off + 4096);
   };
   auto k_store = [&](const half8 (&kr)[4], int slot) {
     char* d = Kl_ + slot * 2 * kKbuf + kdst;
     *reinterpret_cast<half8*>(d) = kr[0];
     *reinterpret_cast<half8*>(d + 4096) = kr[1];
-    if (BK_TERMS == 3) {
-      *reinterpret_cast<half8*>(d + kKbuf) = kr[2];
-      *reinterpret_cast<half8*>(d + kKbuf + 4096) = kr[3];
-    }
+    *reinterpret_cast<half8*>(d + kKbuf) = kr[2];
+    *reinterpret_cast<half8*>(d + kKbuf + 4096) = kr[3];
   };
   half8 kr[4];                     // K tile n+5 on its way to the ring (one iteration to land)
   Cursor ck;
@@ -505,25 +501,14 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
       const int sw = ((4 * ks + g) ^ l15) << 4;
       f.a0h[ks] = *reinterpret_cast<const half8*>(kb + l15 * 256 + sw);
       f.a1h[ks] = *reinterpret_cast<const half8*>(kb + (16 + l15) * 256 + sw);
-      if (BK_TERMS == 3) {
-        f.a0l[ks] = *reinterpret_cast<const half8*>(kb + kKbuf + l15 * 256 + sw);
-        f.a1l[ks] = *reinterpret_cast<const half8*>(kb + kKbuf + (16 + l15) * 256 + sw);
-      }
+      f.a0l[ks] = *reinterpret_cast<const half8*>(kb + kKbuf + l15 * 256 + sw);
+      f.a1l[ks] = *reinterpret_cast<const half8*>(kb + kKbuf + (16 + l15) * 256 + sw);
     }
   };
   // S = K^T Q of one tile (log2 domain).  Two accumulator chains (cells 0-15 / 16-31), the three
   // split terms summed inside the chain, small terms first; consecutive MFMAs alternate chains, which
   // is all the distance a dependent 16x16x32 MFMA needs.  Lane result: S[cell 4g + r (+16)][query l15].
   auto s_mfma = [&](const Frags& f, f32x4& s0, f32x4& s1) {
-    if (BK_TERMS == 1) {
-      s0 = s1 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a0h[ks], qh[ks], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a1h[ks], qh[ks], s1, 0, 0, 0);
-      }
-      return;
-    }
     s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a0l[0], qh[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a1l[0], qh[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
@@ -578,13 +563,12 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
     for (int i = 0; i < 4; ++i) {
       const half2 h = {(_Float16)pv[2 * i], (_Float16)pv[2 * i + 1]};
       const unsigned hk = __builtin_bit_cast(unsigned, h);
-      unsigned lk = 0;   // lo = fp16(p - hi): fp32 subtract and one rounding, straight into its half
+      unsigned lk;   // lo = fp16(p - hi): fp32 subtract and one rounding, straight into its half
       // hipcc does not pad hazards around inline asm (cdna_hip_programming.md 5.7 item 2).  The inputs come
       // straight from v_exp_f32 / v_cvt_pk (a transcendental result needs one wait state before a VALU reads
       // it) and v_fma_mixhi reads the register v_fma_mixlo has just written with a destination half-select
       // (one more): without the s_nops one producer wave occasionally published a wrong lo plane -- errors of
       // ~5e-3 on 16 queries of one launch in thirty (tests/stress_race.py).
-      if (BK_TERMS == 3)
       asm("s_nop 0\n\t"
           "v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
           "s_nop 0\n\t"
@@ -596,7 +580,7 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
     }
     char* pb = Pl_ + pbuf * kPbuf + wave * 2048 + lane * 16;
     *reinterpret_cast<u32x4*>(pb) = ph;
-    if (BK_TERMS == 3) *reinterpret_cast<u32x4*>(pb + 1024) = plo;
+    *reinterpret_cast<u32x4*>(pb + 1024) = plo;
     if (g == 0) Al[pbuf * kQT + l15 * 4 + wave] = alpha;
   };
 
@@ -693,7 +677,7 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
 #pragma unroll
     for (int dt = 0; dt < kCDT; ++dt) {
       vh[dt] = *reinterpret_cast<const half8*>(b.vh + off + dt * 1024);
-      if (BK_TERMS == 3) vl[dt] = *reinterpret_cast<const half8*>(b.vl + off + dt * 1024);
+      vl[dt] = *reinterpret_cast<const half8*>(b.vl + off + dt * 1024);
     }
   }
 #pragma unroll
@@ -713,7 +697,7 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       bh[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + lane * 16);
-      if (BK_TERMS == 3) bl[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + 1024 + lane * 16);
+      bl[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + 1024 + lane * 16);
     }
     const int l1 = cv.seek(jt0 + n + 1);             // refill source: tile n+1 (clamped past the end)
     const size_t noff = v_tile(cv.tt, l1);
@@ -733,14 +717,12 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
 #pragma unroll
     for (int dt = 0; dt < kCDT; ++dt) {
 #if !(BK_ABLATE & 2)
-      if (BK_TERMS == 3) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
-          acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[dt], bh[it], acc[dt][it], 0, 0, 0);
+      for (int it = 0; it < 4; ++it)
+        acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[dt], bh[it], acc[dt][it], 0, 0, 0);
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
-          acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[dt], bl[it], acc[dt][it], 0, 0, 0);
-      }
+      for (int it = 0; it < 4; ++it)
+        acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[dt], bl[it], acc[dt][it], 0, 0, 0);
 #pragma unroll
       for (int it = 0; it < 4; ++it)
         acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[dt], bh[it], acc[dt][it], 0, 0, 0);
@@ -751,7 +733,7 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
         vl[dt] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(nvl + dt * 1024));
 #else
         vh[dt] = *reinterpret_cast<const half8*>(nvh + dt * 1024);
-        if (BK_TERMS == 3) vl[dt] = *reinterpret_cast<const half8*>(nvl + dt * 1024);
+        vl[dt] = *reinterpret_cast<const half8*>(nvl + dt * 1024);
 #endif
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE (the scheduler sinks them to the end)
@@ -770,6 +752,322 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
 
 }
 
+// ================================================================================================================
+// fp16-operand mode (RMNET_BANK_F16): hi planes only -- K, V, the query and P enter the MFMAs rounded to fp16 (11
+// significant bits), fp32 accumulate.  One MFMA term instead of three, and half the bank bytes.  The LDS slots and
+// registers that carry the lo planes in the split mode carry a SECOND memory tile here, so a barrier step covers
+// 64 memory cells (two tiles of the walk, which may belong to different frames).  With a third of the MFMA work
+// per cell the step is bound by latencies, not by the matrix pipe (trace: tools/bk_trace.py), so the pipeline is
+// one stage deeper than the split mode's and nobody starts an iteration with a round trip to LDS:
+//   producers (waves 0-3), iteration n: S(n+3) from fragments read one iteration ago (16 MFMAs, four chains);
+//              soft-max(n+2) -> P[(n+2) % 3]; fragments of K(n+4) from ring slot n % 4.  The soft-max denominator
+//              is the sum of the ROUNDED weights (an MFMA against an all-ones fragment), so the weights that
+//              multiply V sum to one exactly as normalised: a peaked soft-max returns its cell's value with V's
+//              rounding only.  The cell counts of a ragged step come from LDS one iteration ahead as well.
+//   consumers (waves 4-11), iteration n: O += V(n) P(n), 32 MFMAs, P(n) already in registers; V(n+1) bank ->
+//              registers behind each channel tile's MFMAs; P(n+1) (published an iteration ago, triple buffer)
+//              LDS -> registers behind the last channel tile; K(n+5) registers -> ring slot (n+1) % 4 and the
+//              request for K(n+6) (they wait at the barrier in this mode; the producers are the critical path).
+// Barriers: A (K steps 0..3 in the ring), B (P(0), P(1) published; ring slot 0 read), C (K step 4 in slot 0),
+// then one per step.
+// ================================================================================================================
+__device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
+                                         const int* tpre, const int* tarea, int wave, int lane, long long t_entry,
+                                         float& m_out, float& l_out) {
+  const BankView& b = a.b;
+  const int o = wk.o;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int jt0 = wk.jt0, ntl = wk.ntl;
+  const int nst = (ntl + 1) >> 1;                    // steps of two tiles (the last one may be half empty)
+#if BK_TRACE
+  long long* trc = reinterpret_cast<long long*>(a.ws_o + (size_t)a.trace_slot * (size_t)kDo * kQT);
+  int trn = 0;
+  const bool trace_on = blockIdx.x == 0 && wave == 0 && lane == 0;
+  if (trace_on) trc[trn++] = t_entry;
+#endif
+  BK_STAMP();
+  half8 qh[4];
+  {
+    const int qn = wk.qt * kQT + wave * 16 + l15;
+    const bool qvalid = qn < wk.Mq;
+    int cell = 0;
+    if (qvalid) {
+      const int rw = wk.qr.width(), ry = qn / rw;
+      cell = (wk.qr.cy0 + ry) * b.w + wk.qr.cx0 + (qn - ry * rw);
+    }
+    const float* qb = a.qk + (size_t)o * kDe * b.hw + cell;
+    const float keep = qvalid ? a.qscale : 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qh[ks][e] = (_Float16)(qb[(size_t)(32 * ks + 8 * g + e) * b.hw] * keep);
+  }
+  float mref = -INFINITY, lsum = 0.0f;
+  half8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (_Float16)1.0f;
+
+  struct Frags { half8 a0[4], a1[4], b0[4], b1[4]; };   // tile A cells 0-15 / 16-31, tile B cells 0-15 / 16-31
+  auto k_frags = [&](Frags& f, int kslot) {             // 16 conflict-free ds_read_b128 (XOR-swizzled rows)
+    const char* kb = Kl_ + kslot * 2 * kKbuf;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int sw = ((4 * ks + g) ^ l15) << 4;
+      f.a0[ks] = *reinterpret_cast<const half8*>(kb + l15 * 256 + sw);
+      f.a1[ks] = *reinterpret_cast<const half8*>(kb + (16 + l15) * 256 + sw);
+      f.b0[ks] = *reinterpret_cast<const half8*>(kb + kKbuf + l15 * 256 + sw);
+      f.b1[ks] = *reinterpret_cast<const half8*>(kb + kKbuf + (16 + l15) * 256 + sw);
+    }
+  };
+  struct S4 { f32x4 s[4]; };
+  auto s_mfma = [&](const Frags& f, S4& r) {         // four independent chains, interleaved
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r.s[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      r.s[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a0[ks], qh[ks], r.s[0], 0, 0, 0);
+      r.s[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a1[ks], qh[ks], r.s[1], 0, 0, 0);
+      r.s[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.b0[ks], qh[ks], r.s[2], 0, 0, 0);
+      r.s[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.b1[ks], qh[ks], r.s[3], 0, 0, 0);
+    }
+  };
+  // nva / nvb = cells of the step's two tiles that exist (0 for a phantom tile past the split's end).  Its own basic
+  // block (wave-uniform branch), so that the rest of an iteration is ONE scheduling region.
+  auto mask_ragged = [&](S4& r, int nva, int nvb) {
+    if (nva < kJT || nvb < kJT) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        r.s[0][i] = (4 * g + i < nva) ? r.s[0][i] : -INFINITY;
+        r.s[1][i] = (16 + 4 * g + i < nva) ? r.s[1][i] : -INFINITY;
+        r.s[2][i] = (4 * g + i < nvb) ? r.s[2][i] : -INFINITY;
+        r.s[3][i] = (16 + 4 * g + i < nvb) ? r.s[3][i] : -INFINITY;
+      }
+    }
+  };
+  auto soft_max = [&](const S4& r, int pbuf) {
+    float sv[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sv[4 * c + i] = r.s[c][i];
+    float tmax = sv[0];
+#pragma unroll
+    for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, sv[e]);
+    tmax = group4_max(tmax);
+    const bool bump = tmax > mref + kDeferRaw;
+    const float alpha = bump ? __builtin_amdgcn_exp2f((mref - tmax) * kSraw) : 1.0f;
+    mref = bump ? tmax : mref;
+    const float nm = -mref * kSraw;
+    u32x4 pa, pb_;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const half2 ha = {(_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sv[2 * i], kSraw, nm)),
+                        (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sv[2 * i + 1], kSraw, nm))};
+      const half2 hb = {(_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sv[8 + 2 * i], kSraw, nm)),
+                        (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sv[8 + 2 * i + 1], kSraw, nm))};
+      pa[i] = __builtin_bit_cast(unsigned, ha);
+      pb_[i] = __builtin_bit_cast(unsigned, hb);
+    }
+    char* pb = Pl_ + pbuf * kPbuf + wave * 2048 + lane * 16;
+    *reinterpret_cast<u32x4*>(pb) = pa;
+    *reinterpret_cast<u32x4*>(pb + 1024) = pb_;
+    if (g == 0) Al[pbuf * kQT + l15 * 4 + wave] = alpha;
+    // denominator: every row of ones x P is the column sum of the rounded weights of query l15
+    f32x4 lc = {lsum * alpha, 0.f, 0.f, 0.f};
+    lc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, __builtin_bit_cast(half8, pa), lc, 0, 0, 0);
+    lc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, __builtin_bit_cast(half8, pb_), lc, 0, 0, 0);
+    lsum = lc[0];
+  };
+  Cursor cs;                       // walks ahead of the soft-max: the cell counts of a step are fetched an iteration early
+  cs.init(tpre, wk.t, jt0 + ntl - 1);
+  auto step_valid = [&](int step, int& nva, int& nvb) {
+    const int ja = jt0 + 2 * step;
+    const int la = cs.seek(ja);
+    nva = ja < jt0 + ntl ? tarea[cs.tt] - la * kJT : 0;
+    const int lb = cs.seek(ja + 1);
+    nvb = ja + 1 < jt0 + ntl ? tarea[cs.tt] - lb * kJT : 0;
+  };
+  S4 sp;                           // S of the step whose soft-max comes next
+  Frags f;
+  int nva, nvb;                    // cell counts of that step
+  __syncthreads();                                   // A: K steps 0..3 in the ring
+  {
+    S4 s0, s1;
+    k_frags(f, 0);
+    s_mfma(f, s0);
+    k_frags(f, 1);
+    s_mfma(f, s1);
+    k_frags(f, 2);
+    s_mfma(f, sp);
+    step_valid(0, nva, nvb);
+    mask_ragged(s0, nva, nvb);
+    soft_max(s0, 0);
+    step_valid(1, nva, nvb);
+    mask_ragged(s1, nva, nvb);
+    soft_max(s1, 1);
+    k_frags(f, 3);
+    step_valid(2, nva, nvb);
+  }
+  __syncthreads();                                   // B: P(0), P(1) visible; ring slot 0 free
+  __syncthreads();                                   // C: K step 4 in slot 0
+  BK_STAMP();
+  int pbuf = 2;                                      // (n + 2) % 3
+  for (int n = 0; n < nst; ++n) {
+    BK_STAMP();   // loop top
+    mask_ragged(sp, nva, nvb);
+    __builtin_amdgcn_sched_barrier(0);
+    BK_STAMP();   // (head)
+    S4 s0;
+    s_mfma(f, s0);                                   // step n+3
+    soft_max(sp, pbuf);                              // step n+2
+    // one S MFMA, then a few soft-max VALU instructions, and so on: issued back to back the 16 MFMAs of this wave wait
+    // for the pipe behind the consumers' (~40 cycles each, trace) while its VALU chain sits behind them in program order
+#if BK_F16_INTERLEAVE
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, BK_F16_INTERLEAVE, 0);
+    }
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    BK_STAMP();   // S MFMAs + soft-max done
+    sp = s0;
+    k_frags(f, n & 3);                               // step n+4
+    step_valid(n + 3, nva, nvb);                     // (LDS round trips: they end under the barrier)
+    pbuf = pbuf == 2 ? 0 : pbuf + 1;
+    BK_STAMP();   // K frags requested
+    __syncthreads();
+    BK_STAMP();   // after barrier
+  }
+  m_out = mref * kSraw;
+  l_out = lsum;
+  BK_STAMP();
+}
+
+__device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
+                                         const int* tpre, int wave, int lane, long long t_entry,
+                                         f32x4 (&acc)[kCDT][4]) {
+  const BankView& b = a.b;
+  const int o = wk.o;
+  const int l15 = lane & 15;
+  const int jt0 = wk.jt0, ntl = wk.ntl;
+  const int nst = (ntl + 1) >> 1;
+#if BK_TRACE
+  long long* trc = reinterpret_cast<long long*>(a.ws_o + (size_t)a.trace_slot * (size_t)kDo * kQT) + 1024;
+  int trn = 0;
+  const bool trace_on = blockIdx.x == 0 && wave == BK_TRACE_WAVE && lane == 0;
+  if (trace_on) trc[trn++] = t_entry;
+#endif
+  BK_STAMP();
+  const size_t so0 = (size_t)o * b.Tcap;
+  const size_t tiles_per_slot = (size_t)(b.hwp / kJT);
+  const int dt0 = kCDT * (wave - kProducers);
+  const size_t vlane = (size_t)(dt0 * 64 + lane) * 16;
+  auto v_tile = [&](int tt, int ll) { return ((so0 + tt) * tiles_per_slot + ll) * (size_t)(kDo * kJT * 2) + vlane; };
+  // K ring: ring slot = step & 3; plane 0 of a slot = the step's first tile, plane 1 = its second tile (hi planes
+  // both).  A tile is one contiguous 8 KB block = 512 chunks of 16 B; consumer thread ct moves chunk ct of both
+  // tiles.  LDS image as in the split mode: row = cell (256 B), chunk c of row r stored at chunk c ^ (r & 15).
+  const int ct = (wave - kProducers) * 64 + lane;
+  const int crow = ct >> 4;
+  const int kdst = crow * 256 + (((ct & 15) ^ (crow & 15)) << 4);
+  Cursor ck;
+  ck.init(tpre, wk.t, jt0 + ntl - 1);
+  auto k_load = [&](half8 (&kr)[2], int step) {      // both tiles of a step (clamped past the end)
+    const int la = ck.seek(jt0 + 2 * step);
+    kr[0] = *reinterpret_cast<const half8*>(b.kh + ((so0 + ck.tt) * b.hwp + (size_t)la * kJT) * kDe * sizeof(_Float16) + (size_t)ct * 16);
+    const int lb = ck.seek(jt0 + 2 * step + 1);
+    kr[1] = *reinterpret_cast<const half8*>(b.kh + ((so0 + ck.tt) * b.hwp + (size_t)lb * kJT) * kDe * sizeof(_Float16) + (size_t)ct * 16);
+  };
+  auto k_store = [&](const half8 (&kr)[2], int slot) {
+    char* d = Kl_ + slot * 2 * kKbuf + kdst;
+    *reinterpret_cast<half8*>(d) = kr[0];
+    *reinterpret_cast<half8*>(d + kKbuf) = kr[1];
+  };
+  half8 kr[2];                     // the step on its way to the ring (one iteration to land)
+  {
+    half8 k0[2], k1[2], k2[2], k3[2];
+    k_load(k0, 0);
+    k_load(k1, 1);
+    k_load(k2, 2);
+    k_load(k3, 3);
+    k_load(kr, 4);
+    k_store(k0, 0);
+    k_store(k1, 1);
+    k_store(k2, 2);
+    k_store(k3, 3);
+  }
+  half8 va[kCDT], vb[kCDT];        // V fragments of the step's two tiles
+  Cursor cv;
+  cv.init(tpre, wk.t, jt0 + ntl - 1);
+  {
+    const int la = cv.seek(jt0);
+    const size_t offa = v_tile(cv.tt, la);
+    const int lb = cv.seek(jt0 + 1);
+    const size_t offb = v_tile(cv.tt, lb);
+#pragma unroll
+    for (int dt = 0; dt < kCDT; ++dt) {
+      va[dt] = *reinterpret_cast<const half8*>(b.vh + offa + dt * 1024);
+      vb[dt] = *reinterpret_cast<const half8*>(b.vh + offb + dt * 1024);
+    }
+  }
+#pragma unroll
+  for (int dt = 0; dt < kCDT; ++dt)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) acc[dt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+  half8 pa[4], pb[4];              // P fragments of the current step
+  f32x4 al;                        // its rescale factors
+  auto p_frags = [&](int buf) {
+    const char* pfr = Pl_ + buf * kPbuf;
+    al = *reinterpret_cast<const f32x4*>(Al + buf * kQT + l15 * 4);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      pa[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + lane * 16);
+      pb[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + 1024 + lane * 16);
+    }
+  };
+  __syncthreads();                                   // A: K steps 0..3 in the ring
+  __syncthreads();                                   // B: P(0), P(1) visible; ring slot 0 free
+  k_store(kr, 0);                                    // step 4
+  k_load(kr, 5);
+  p_frags(0);
+  __syncthreads();                                   // C
+  BK_STAMP();
+  int pnext = 1;                                     // (n + 1) % 3
+  for (int n = 0; n < nst; ++n) {
+    BK_STAMP();   // loop top
+    k_store(kr, (n + 1) & 3);                        // step n+5 (its slot was last read in iteration n-3)
+    k_load(kr, n + 6);
+    const int la = cv.seek(jt0 + 2 * n + 2);          // refill source: step n+1 (clamped past the end)
+    const char* nva = b.vh + v_tile(cv.tt, la);
+    const int lb = cv.seek(jt0 + 2 * n + 3);
+    const char* nvb = b.vh + v_tile(cv.tt, lb);
+    if (__any(al[0] != 1.0f || al[1] != 1.0f || al[2] != 1.0f || al[3] != 1.0f)) {
+#pragma unroll
+      for (int dt = 0; dt < kCDT; ++dt)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) acc[dt][it] *= al[it];
+    }
+#pragma unroll
+    for (int dt = 0; dt < kCDT; ++dt) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va[dt], pa[it], acc[dt][it], 0, 0, 0);
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[dt], pb[it], acc[dt][it], 0, 0, 0);
+      va[dt] = *reinterpret_cast<const half8*>(nva + dt * 1024);
+      vb[dt] = *reinterpret_cast<const half8*>(nvb + dt * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    p_frags(pnext);                                  // step n+1: published an iteration ago; lands under the barrier
+    pnext = pnext == 2 ? 0 : pnext + 1;
+    BK_STAMP();   // PV done
+    __syncthreads();
+    BK_STAMP();   // after barrier
+  }
+  BK_STAMP();
+}
+
 constexpr int kMaxObj = kBankMaxObj;    // objects planned together in one launch (the launcher groups more)
 
 // Partial slots of one (object, query tile) pair: a strided run (the aligned column blocks) followed by a run of
@@ -781,7 +1079,7 @@ struct PairSlots {
 __device__ inline PairSlots pair_slots(int sb, int nqt, const BankChunks& bc, int qt) {
   PairSlots r{sb + qt, bc.nfull, nqt, 0, bc.nfull, 0};
   if (bc.R > 0) {
-    const int v0 = qt * (bc.R + kSegCost);                                   // the pair on the virtual line
+    const int v0 = qt * (bc.R + bc.sc);                                   // the pair on the virtual line
     r.cf = v0 / bc.C;
     const int cl = (v0 + bc.R - 1) / bc.C;                                   // remainder chunks touching it
     r.b0 = sb + nqt * bc.nfull + r.cf + qt;
@@ -815,7 +1113,7 @@ constexpr int kStaticRowsPerTicket = BK_STATIC_ROWS;            // (object, chan
 #define BK_STATIC_BPUS 35.0e3f
 #endif
 constexpr float kStaticBytesPerUs = BK_STATIC_BPUS;             // what one streaming workgroup moves (sizing of the set-aside)
-constexpr float kTileUs = 1.75f, kLaunchUs = 12.0f;             // tile step / fixed part of a compute workgroup (same estimate)
+constexpr float kTileUs = 1.75f, kTileUsF16 = 0.55f, kLaunchUs = 12.0f;   // tile step / fixed part of a compute workgroup (same estimate)
 static_assert(kSplitMax * kQT * 4 <= 2 * kPbuf, "merge weights live in the P buffers");
 static_assert(kConsumers * 16 * 65 * 4 + 2 * 4 * kQT * 4 <= 8 * kKbuf, "epilogue scratch lives in the K ring");
 
@@ -834,6 +1132,7 @@ static_assert(kConsumers * 16 * 65 * 4 + 2 * 4 * kQT * 4 <= 8 * kKbuf, "epilogue
 // publish their partial (O, m, l) with write-through stores and count themselves done; the LAST arriver keeps its
 // partial in registers, waits until the others are done (they are past their loops: the wait cannot deadlock,
 // whatever is resident), merges the pair and writes its read-out.
+template <int kTerms>
 __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
   __shared__ int o_njt[kMaxObj], o_m[kMaxObj], o_nqt[kMaxObj], o_cb[kMaxObj], o_sb[kMaxObj];
@@ -841,8 +1140,8 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   __shared__ int plan_n, plan_c, sflag;
   char* Kl_ = lds;                                 // [ring slot][plane][8 KB]
   char* Pl_ = lds + 8 * kKbuf;                     // [buf][ntile][plane][lane*16]
-  float* Al = reinterpret_cast<float*>(Pl_ + 2 * kPbuf);
-  int* tpre = reinterpret_cast<int*>(Al + 2 * kQT);
+  float* Al = reinterpret_cast<float*>(Pl_ + 3 * kPbuf);
+  int* tpre = reinterpret_cast<int*>(Al + 3 * kQT);
   int* tarea = tpre + kMaxT + 4;
 
   const long long t_entry = (long long)__builtin_readcyclecounter();
@@ -909,15 +1208,18 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     int target = a.target;
     if (!(BK_ABLATE & 256)) {
       const float static_bytes = (float)ng * (float)hw * (float)kDo * 4.0f * 2.5f;
-      const float compute_us = kLaunchUs + kTileUs * (float)W / (float)a.target;
+      const float compute_us = kLaunchUs + (kTerms == 1 ? kTileUsF16 : kTileUs) * (float)W / (float)a.target;
       int aside = (int)(static_bytes / (compute_us * kStaticBytesPerUs) + 0.5f);
       aside = min(aside, a.target / 4);
       target = a.target - aside;
     }
     // smallest chunk length whose chunks fit `target` workgroups (sum_o nch(o) shrinks as C grows)
+    constexpr int kSC = kTerms == 1 ? kSegCostF16 : kSegCost;
+    constexpr int kCq = kTerms == 1 ? 2 : 1;              // (fp16 mode: a step is two tiles, an odd chunk wastes half of one)
     int C0 = max((W + target - 1) / target, bank_chunk_min(njt_max));
-    for (int it = 0; it < 1024 && wave_sum(bank_chunks(nqt, njt, C0).nch) > target; ++it) C0 += 1 + (C0 >> 5);
-    const BankChunks bc0 = bank_chunks(nqt, njt, C0);
+    C0 = (C0 + kCq - 1) / kCq * kCq;
+    for (int it = 0; it < 1024 && wave_sum(bank_chunks(nqt, njt, C0, kSC).nch) > target; ++it) C0 += (1 + (C0 >> 5) + kCq - 1) / kCq * kCq;
+    const BankChunks bc0 = bank_chunks(nqt, njt, C0, kSC);
     int nch = bc0.nch, nsl = bc0.nch + (bc0.R > 0 ? nqt : 0);   // chunks; slots (a remainder chunk can add one per query tile)
     const int my_ch = nch, my_sl = nsl;
 #pragma unroll
@@ -955,7 +1257,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   for (int i = 1; i < ng; ++i)
     if (sld(o_cb[i]) <= c) og = i;          // (objects without chunks share the next one's base: the later one wins)
   const int nqt = sld(o_nqt[og]), njt = sld(o_njt[og]);
-  const BankChunks bc = bank_chunks(nqt, njt, C);
+  const BankChunks bc = bank_chunks(nqt, njt, C, kTerms == 1 ? kSegCostF16 : kSegCost);
   const int cl = c - sld(o_cb[og]);         // chunk inside the object
   const int lane = tid & 63;
   Walk wk;
@@ -1012,10 +1314,17 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
 #if BK_CLK
     if (tid == 0 && clk_rec[5] == 0) clk_rec[5] = (long long)__builtin_amdgcn_s_memrealtime() - t_real;   // first segment starts
 #endif
-    if (producer)
-      producer_loop(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, ln, t_entry, m_seg, l_seg);
-    else
-      consumer_loop(a, wk, Kl_, Pl_, Al, tpre, wave, ln, t_entry, acc);
+    if constexpr (kTerms == 1) {
+      if (producer)
+        producer_loop_f16(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, ln, t_entry, m_seg, l_seg);
+      else
+        consumer_loop_f16(a, wk, Kl_, Pl_, Al, tpre, wave, ln, t_entry, acc);
+    } else {
+      if (producer)
+        producer_loop(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, ln, t_entry, m_seg, l_seg);
+      else
+        consumer_loop(a, wk, Kl_, Pl_, Al, tpre, wave, ln, t_entry, acc);
+    }
 #if BK_CLK
     if (tid == kRThreads - 1) clk_rec[6] = (long long)__builtin_amdgcn_s_memrealtime() - t_real;          // (last) tile loop over
 #endif
@@ -1242,7 +1551,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   }
   // remainder chunk: units [u0, u1) of the virtual line over the last R tile columns (common.h)
   const int cr = cl - nqt * bc.nfull;
-  const int u0 = cr * C, u1 = u0 + C, span = bc.R + kSegCost;
+  const int u0 = cr * C, u1 = u0 + C, span = bc.R + bc.sc;
   bool first = true;
   for (int qt = u0 / span; qt < nqt && qt * span < u1; ++qt) {
     const int j0 = max(u0 - qt * span, 0), j1 = min(u1 - qt * span, bc.R);   // tiles of pair qt inside the chunk
@@ -1524,7 +1833,10 @@ int launch_bank_main(const BankReadArgs& m, hipStream_t st) {
     a.nobj = m.no - obj0 < kMaxObj ? m.no - obj0 : kMaxObj;
     a.slot0 = bank_group_slot0(obj0, m.h * m.w);
     a.target = kSplitTargetSlots;
-    hipLaunchKernelGGL(bk_main, dim3(a.target), dim3(kRThreads), 0, st, a);
+    if (m.f16)
+      hipLaunchKernelGGL(bk_main<1>, dim3(a.target), dim3(kRThreads), 0, st, a);
+    else
+      hipLaunchKernelGGL(bk_main<3>, dim3(a.target), dim3(kRThreads), 0, st, a);
     if (int e = check_launch()) return e;
   }
   return RMNET_OK;

@@ -167,13 +167,18 @@ constexpr int kPlanInts = 12;
 #define RMNET_SEG_COST 6   // (4 until round 3: a segment now also ends with a publish / ticket / merge)
 #endif
 constexpr int kSegCost = RMNET_SEG_COST;
-struct BankChunks { int C, nfull, R, nrem, nch; };
-__host__ __device__ inline BankChunks bank_chunks(int nqt, int njt, int C) {
+#ifndef RMNET_SEG_COST_F16
+#define RMNET_SEG_COST_F16 12   // fp16-operand mode: a tile costs a third, a segment's fixed part does not
+#endif
+constexpr int kSegCostF16 = RMNET_SEG_COST_F16;
+struct BankChunks { int C, nfull, R, nrem, nch, sc; };
+__host__ __device__ inline BankChunks bank_chunks(int nqt, int njt, int C, int segcost = kSegCost) {
   BankChunks k;
   k.C = C;
+  k.sc = segcost;
   k.nfull = njt / C;
   k.R = njt - k.nfull * C;
-  k.nrem = k.R > 0 ? (nqt * (k.R + kSegCost) - kSegCost + C - 1) / C : 0;
+  k.nrem = k.R > 0 && nqt > 0 ? (nqt * (k.R + segcost) - segcost + C - 1) / C : 0;   // (no query tile: no chunk)
   k.nch = nqt * k.nfull + k.nrem;
   return k;
 }
@@ -211,6 +216,7 @@ struct BankReadArgs {
   hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_end = nullptr;
   int gate = 0;               // != 0: bk_main returns at once when the bank's overflow word is set
   const int32_t* T_dev = nullptr;   // optional device-resident frame counter added to T
+  int f16 = 0;                // != 0: fp16-operand mode (hi planes only, one MFMA term)
 };
 int launch_bank_append(void* bank, int no, int Tcap, int h, int w, int slot, const float* k4,
                        const float* v4, const int32_t* rects, hipStream_t st, const int32_t* slot_dev = nullptr);

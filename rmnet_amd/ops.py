@@ -167,15 +167,28 @@ def memory_read(m_key, m_val, q_key, q_val, mem_rects=None, qry_rects=None, want
     return out, p
 
 
+BANK_F16 = 4                      # include/rmnet_hip.h: RMNET_BANK_F16 (== RMNET_MR_F16)
+MR_F16 = 4
+
+
+def _precision(p):
+    """'split': K, V, q and P enter the MFMAs as fp16 hi/lo pairs, three terms, fp32-class accuracy (default).
+    'f16': hi planes only -- fp16 operands, fp32 accumulate, about 2^-11 relative (include/rmnet_hip.h)."""
+    if p not in ('split', 'f16'):
+        raise ValueError("precision must be 'split' or 'f16'")
+    return p
+
+
 class MemoryBank:
     """Device-resident regional memory of one clip: ``no`` objects x ``capacity`` frame slots on an
     h x w feature grid (csrc/bank.hip).  ``append`` writes a slot from the un-masked KeyValue outputs
     and the frame's cell rectangles; ``read`` runs the fused regional read over the first T slots."""
 
-    def __init__(self, no, capacity, h, w, device):
+    def __init__(self, no, capacity, h, w, device, precision='split'):
         lib = _lib.load()
         self.no, self.capacity, self.h, self.w = int(no), int(capacity), int(h), int(w)
         self.device = torch.device(device)
+        self.precision = _precision(precision)        # arithmetic of ``read``: 'split' (fp32-class, default) or 'f16'
         nb = lib.rmnet_bank_bytes(self.no, self.capacity, self.h, self.w)
         if nb == 0:
             raise RuntimeError('invalid bank geometry')
@@ -259,7 +272,7 @@ class MemoryBank:
                 ws = _ws(lib.rmnet_bank_read_workspace_bytes(self.no, self.h, self.w), self.device)
             ev = [ctypes.c_void_p(e) if e else None for e in (events or (None, None, None))]
             rc = lib.rmnet_bank_read_f32_at(_ptr(self.blob), self.no, self.capacity, self.h, self.w, int(T), _ptr(_t_dev),
-                                            _ptr(q_key), _ptr(q_val), _ptr(qry_rects), _ptr(out), _ptr(ws),
+                                            BANK_F16 if self.precision == 'f16' else 0, _ptr(q_key), _ptr(q_val), _ptr(qry_rects), _ptr(out), _ptr(ws),
                                             ws.numel(), _stream(self.device), ev[0], ev[1], ev[2])
         _lib.check(rc, 'rmnet_bank_read_f32_at')
         return out

@@ -46,14 +46,16 @@ class MemoryReader(nn.Module):
     only computed when ``return_affinity=True``; otherwise the second element is ``None``.
     Optional ``mem_rects`` / ``qry_rects`` select the fused regional form."""
 
-    def __init__(self, return_affinity=False):
+    def __init__(self, return_affinity=False, precision='split'):
         super().__init__()
         self.return_affinity = return_affinity
+        self.precision = ops._precision(precision)     # 'f16': fp16 operands, about twice as fast, ~2^-11 relative (ops.MR_F16)
 
     def forward(self, m_key, m_val, q_key, q_val, mem_rects=None, qry_rects=None, T=None):
         return ops.memory_read(m_key.contiguous(), m_val.contiguous(), q_key.contiguous(),
                                q_val.contiguous(), mem_rects, qry_rects,
-                               want_p=self.return_affinity, T=T)
+                               want_p=self.return_affinity, T=T,
+                               flags=ops.MR_F16 if self.precision == 'f16' else 0)
 
 
 class RMNet(nn.Module):
@@ -62,9 +64,13 @@ class RMNet(nn.Module):
     ``torch.no_grad()`` and refuse to run in training mode (the reference's training path -- losses,
     DataParallel, models/rmnet.py's ``self.training`` branches -- is out of scope)."""
 
-    def __init__(self, cfg=None):
+    def __init__(self, cfg=None, read_precision='split'):
         super().__init__()
         self.cfg = cfg
+        # arithmetic of the bank read in the frame loop: 'split' = fp16 hi/lo pairs, fp32-class (default);
+        # 'f16' = fp16 operands with fp32 accumulate, about twice as fast, ~2^-11 relative per read-out -- inside the
+        # reference task's bar (mask IoU within 1e-3, tests/test_gpu_parity.py) but not fp32-class
+        self.read_precision = ops._precision(read_precision)
         self.encoder_memory = EncoderMemory()
         self.encoder_query = EncoderQuery()
         self.kv_memory = KeyValue(1024, keydim=128, valdim=512)
@@ -296,10 +302,11 @@ class RMNet(nn.Module):
 
     def new_bank(self, ctx, capacity, exact=False):
         """Pre-allocated regional memory for one clip (replaces models/rmnet.py:191-205, 416-426): the
-        split-fp16 ``MemoryBank``, or -- for more than 512 memorised frames, or ``exact`` -- plain fp32
+        split-fp16 ``MemoryBank``, or -- for more than 2048 memorised frames, or ``exact`` -- plain fp32
         tensors read by the exact-fp32 kernel (``TensorBank``)."""
-        cls = ops.TensorBank if exact or capacity > ops.BANK_MAX_SLOTS else ops.MemoryBank
-        return cls(len(ctx.flat), capacity, ctx.h, ctx.w, ctx.device)
+        if exact or capacity > ops.BANK_MAX_SLOTS:
+            return ops.TensorBank(len(ctx.flat), capacity, ctx.h, ctx.w, ctx.device)
+        return ops.MemoryBank(len(ctx.flat), capacity, ctx.h, ctx.w, ctx.device, precision=self.read_precision)
 
     @torch.no_grad()
     def frame_step(self, ctx, bank, prev_frame, prev_mask, cur_frame, cur_flow, commit):

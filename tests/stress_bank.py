@@ -31,7 +31,7 @@ for case in range(cases):
         return (x0, rng.randint(x0, w), y0, rng.randint(y0, h))
     mr = np.array([[rect(0.2, 0.2) for _ in range(T)] for _ in range(no)], np.int32)
     qr = np.array([rect(0.1, 0.2) for _ in range(no)], np.int32)
-    bank = ops.MemoryBank(no, T + int(rng.randint(0, 3)), h, w, dev)
+    bank = ops.MemoryBank(no, T + int(rng.randint(0, 3)), h, w, dev, precision=os.environ.get('RMNET_BANK_PRECISION', 'split'))
     for t in range(T):
         bank.append(t, cu(mk[:, :, t]), cu(mv[:, :, t]), cu(mr[:, t]))
     got = bank.read(T, cu(qk), cu(qv), cu(qr)).cpu().numpy()

@@ -30,7 +30,7 @@ for case, (no, T, h, w, seed) in enumerate([(2, 3, 6, 10, 5), (1, 5, 8, 8, 1), (
         qr = np.array([rect() for _ in range(no)], np.int32)
     mk[:, :, T - 1, h - 1, w - 1] = qk[:, :, min(2, h - 1), min(3, w - 1)] * 9.0     # late spike
     want, _ = oracle.regional_memory_read(mk, mv, qk, qv, mr, qr)
-    bank = ops.MemoryBank(no, T + 1, h, w, dev)
+    bank = ops.MemoryBank(no, T + 1, h, w, dev, precision=os.environ.get('RMNET_BANK_PRECISION', 'split'))
     for t in range(T):
         bank.append(t, cu(mk[:, :, t]), cu(mv[:, :, t]), cu(mr[:, t]))
     qk_d, qv_d, qr_d = cu(qk), cu(qv), cu(qr)

@@ -32,7 +32,7 @@ def test_library_builds_and_exports_every_header_symbol():
 def test_error_strings_and_sizes_need_no_gpu():
     from rmnet_amd import _lib
     lib = _lib.load()
-    assert lib.rmnet_abi_version() == 2
+    assert lib.rmnet_abi_version() == 3
     assert lib.rmnet_error_string(0) == b'ok'
     for code in (-1, -2, -3, -4):
         assert len(lib.rmnet_error_string(code)) > 4

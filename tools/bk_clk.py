@@ -18,7 +18,7 @@ qk = (torch.randn(no, 128, h, w, generator=g) * 0.6).to(dev)
 qv = torch.randn(no, 512, h, w, generator=g).to(dev)
 qr = torch.tensor([(2, 2 + qw - 1, 1, 1 + qh - 1)] * no, dtype=torch.int32, device=dev)
 mr = torch.tensor([(3, 3 + mw - 1, 2, 2 + mh - 1)] * no, dtype=torch.int32, device=dev)
-bank = ops.MemoryBank(no, T, h, w, dev)
+bank = ops.MemoryBank(no, T, h, w, dev, precision=os.environ.get('RMNET_BANK_PRECISION', 'split'))
 for t in range(T):
     bank.append(t, mk[:, :, t].contiguous(), mv[:, :, t].contiguous(), mr)
 lib = _lib.load()

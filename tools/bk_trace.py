@@ -4,7 +4,8 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from rmnet_amd import ops, _lib
-no, T, h, w = 1, 5, 30, 54
+no, h, w = 1, 30, 54
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = torch.device('cuda', 0)
 g = torch.Generator().manual_seed(0)
 mk = (torch.randn(no, 128, T, h, w, generator=g) * 0.6).to(dev)
@@ -15,7 +16,7 @@ frac = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 rh, rw = max(1, int(round(h * frac ** 0.5))), max(1, int(round(w * frac ** 0.5)))
 y0, x0 = (h - rh) // 2, (w - rw) // 2
 rect = torch.tensor([[x0, x0 + rw - 1, y0, y0 + rh - 1]] * no, dtype=torch.int32, device=dev)
-bank = ops.MemoryBank(no, T, h, w, dev)
+bank = ops.MemoryBank(no, T, h, w, dev, precision=os.environ.get('RMNET_BANK_PRECISION', 'split'))
 for t in range(T):
     bank.append(t, mk[:, :, t].contiguous(), mv[:, :, t].contiguous(), rect)
 lib = _lib.load()
@@ -27,7 +28,10 @@ torch.cuda.synchronize()
 slots = 256 + no * ((h * w + 1 + 63) // 64)      # bank_total_slots(): the stamps live in the last slot
 off = (slots - 1) * 512 * 64 * 4
 tr = ws[off:off + 2048 * 8].view(torch.int64).cpu().numpy()
-for name, a, labels in (('producer wave0', tr[:1024], ['top->MFMAs issued', 'soft-max', 'K frags', 'barrier', '->next top']),
+f16 = os.environ.get('RMNET_BANK_PRECISION') == 'f16'
+plabels = (['top->head (mask)', 'S MFMAs + soft-max', 'K frags', 'barrier', '->next top'] if f16 else
+           ['top->MFMAs issued', 'soft-max', 'K frags', 'barrier', '->next top'])
+for name, a, labels in (('producer wave0', tr[:1024], plabels),
                         ('consumer wave4', tr[1024:2048], ['top->PV done', 'barrier', '->next top'])):
     a = a[a != 0]
     d = np.diff(a)

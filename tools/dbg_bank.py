@@ -33,7 +33,7 @@ for no, T, h, w, seed in cases:
         qr[0] = (0, w - 1, 0, h - 1)
         mr[1, :] = (1, 0, 1, 0)                    # an object with nothing memorised inside its boxes
     want, _ = oracle.regional_memory_read(mk, mv, qk, qv, mr, qr)
-    bank = ops.MemoryBank(no, T + 1, h, w, dev)
+    bank = ops.MemoryBank(no, T + 1, h, w, dev, precision=os.environ.get('RMNET_BANK_PRECISION', 'split'))
     for t in range(T):
         bank.append(t, cu(mk[:, :, t]), cu(mv[:, :, t]), cu(mr[:, t]))
     got = bank.read(T, cu(qk), cu(qv), cu(qr)).cpu().numpy()

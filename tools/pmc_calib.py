@@ -21,7 +21,7 @@ no, T, h, w = 1, 5, 30, 54
 g = torch.Generator().manual_seed(0)
 k = (torch.randn(no, 128, h, w, generator=g) * 0.6).to(dev)
 v = torch.randn(no, 512, h, w, generator=g).to(dev)
-bank = ops.MemoryBank(no, T, h, w, dev)
+bank = ops.MemoryBank(no, T, h, w, dev, precision=os.environ.get('RMNET_BANK_PRECISION', 'split'))
 full = torch.tensor([[0, w - 1, 0, h - 1]], dtype=torch.int32, device=dev)
 for t in range(T):
     bank.append(t, k, v, full)
