@@ -339,6 +339,12 @@ constexpr int kRThreads = 64 * (kProducers + kConsumers);  // 768 = 12 waves = 3
 #ifndef BK_VNT
 #define BK_VNT 0       // experiments only: non-temporal V fragment loads
 #endif
+#ifndef BK_F16_FRAGS
+#define BK_F16_FRAGS 0 // fp16 mode, producers (experiment): 1 = the next K fragments are requested behind the S MFMAs (measured: no gain), 0 = after the soft-max
+#endif
+#ifndef BK_F16_V
+#define BK_F16_V 0     // fp16 mode, consumers (experiments): 1 K ring mid-step, 2 a V load after every 4 MFMAs
+#endif
 #ifndef BK_F16_INTERLEAVE
 #define BK_F16_INTERLEAVE 6   // fp16 mode, producers: soft-max VALU instructions scheduled between two S MFMAs (0 = as the compiler likes)
 #endif
@@ -918,21 +924,35 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
     __builtin_amdgcn_sched_barrier(0);
     BK_STAMP();   // (head)
     S4 s0;
+#if BK_ABLATE & 4
+    s0 = sp;
+#else
     s_mfma(f, s0);                                   // step n+3
+#if !(BK_ABLATE & 64) && (BK_F16_FRAGS == 1)
+    k_frags(f, n & 3);                               // step n+4: each fragment is requested right behind the MFMA that read
+                                                     // its register, so the 16 KB land under the soft-max, not in front of the barrier
+#endif
     soft_max(sp, pbuf);                              // step n+2
-    // one S MFMA, then a few soft-max VALU instructions, and so on: issued back to back the 16 MFMAs of this wave wait
-    // for the pipe behind the consumers' (~40 cycles each, trace) while its VALU chain sits behind them in program order
+#endif
+    // one S MFMA, its fragment's refill, then a few soft-max VALU instructions, and so on: issued back to back the 16
+    // MFMAs of this wave wait for the pipe behind the consumers' (~40 cycles each, trace) while its VALU chain sits
+    // behind them in program order
 #if BK_F16_INTERLEAVE
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#if BK_F16_FRAGS == 1
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#endif
       __builtin_amdgcn_sched_group_barrier(0x002, BK_F16_INTERLEAVE, 0);
     }
 #endif
     __builtin_amdgcn_sched_barrier(0);
     BK_STAMP();   // S MFMAs + soft-max done
     sp = s0;
+#if !(BK_ABLATE & 64) && (BK_F16_FRAGS != 1)
     k_frags(f, n & 3);                               // step n+4
+#endif
     step_valid(n + 3, nva, nvb);                     // (LDS round trips: they end under the barrier)
     pbuf = pbuf == 2 ? 0 : pbuf + 1;
     BK_STAMP();   // K frags requested
@@ -1033,14 +1053,21 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
   __syncthreads();                                   // C
   BK_STAMP();
   int pnext = 1;                                     // (n + 1) % 3
+  // addresses of the NEXT step's V tiles: found before the barrier, so that an iteration starts with MFMAs
+  const char *nva, *nvb;
+  auto v_next = [&](int step) {
+    const int la = cv.seek(jt0 + 2 * step);          // (clamped past the end)
+    nva = b.vh + v_tile(cv.tt, la);
+    const int lb = cv.seek(jt0 + 2 * step + 1);
+    nvb = b.vh + v_tile(cv.tt, lb);
+  };
+  v_next(1);
   for (int n = 0; n < nst; ++n) {
     BK_STAMP();   // loop top
+#if !(BK_F16_V & 1) && !(BK_ABLATE & 16)
     k_store(kr, (n + 1) & 3);                        // step n+5 (its slot was last read in iteration n-3)
     k_load(kr, n + 6);
-    const int la = cv.seek(jt0 + 2 * n + 2);          // refill source: step n+1 (clamped past the end)
-    const char* nva = b.vh + v_tile(cv.tt, la);
-    const int lb = cv.seek(jt0 + 2 * n + 3);
-    const char* nvb = b.vh + v_tile(cv.tt, lb);
+#endif
     if (__any(al[0] != 1.0f || al[1] != 1.0f || al[2] != 1.0f || al[3] != 1.0f)) {
 #pragma unroll
       for (int dt = 0; dt < kCDT; ++dt)
@@ -1049,18 +1076,46 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
     }
 #pragma unroll
     for (int dt = 0; dt < kCDT; ++dt) {
+#if BK_F16_V & 4
+      // the two consumers of a SIMD take turns at the matrix pipe (the arbiter prefers the older wave: the younger
+      // one would finish every step last)
+      if (((dt ^ (wave >> 3)) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
+#if !(BK_ABLATE & 2)
 #pragma unroll
       for (int it = 0; it < 4; ++it)
         acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va[dt], pa[it], acc[dt][it], 0, 0, 0);
+#endif
+#if BK_F16_V & 2
+      va[dt] = *reinterpret_cast<const half8*>(nva + dt * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+#if !(BK_ABLATE & 2)
 #pragma unroll
       for (int it = 0; it < 4; ++it)
         acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[dt], pb[it], acc[dt][it], 0, 0, 0);
+#endif
+#if !(BK_ABLATE & 1)
+#if !(BK_F16_V & 2)
       va[dt] = *reinterpret_cast<const half8*>(nva + dt * 1024);
+#endif
       vb[dt] = *reinterpret_cast<const half8*>(nvb + dt * 1024);
+#endif
       __builtin_amdgcn_sched_barrier(0);
+#if BK_F16_V & 1
+      if (dt == 1) {                                 // the K ring in the middle of the step, not in everybody's first cycles
+        k_store(kr, (n + 1) & 3);                    // step n+5 (its slot was last read in iteration n-3)
+        k_load(kr, n + 6);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
     }
+#if BK_ABLATE & 32
+    if (n == 0)   // (experiment, wrong results: the P fragments are read once per segment)
+#endif
     p_frags(pnext);                                  // step n+1: published an iteration ago; lands under the barrier
     pnext = pnext == 2 ? 0 : pnext + 1;
+    v_next(n + 2);
     BK_STAMP();   // PV done
     __syncthreads();
     BK_STAMP();   // after barrier

@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from rmnet_amd import ops
 from oracle import oracle
+# RMNET_BANK_PRECISION=f16 runs the fp16-operand mode: its bar is 2^-10 of the largest value (tests/test_gpu_parity.py)
+ATOL = 5e-3 if os.environ.get('RMNET_BANK_PRECISION') == 'f16' else 3e-5
 dev = torch.device('cuda', 0)
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -38,7 +40,7 @@ for case in range(cases):
     want, _ = oracle.regional_memory_read(mk, mv, qk, qv, mr, qr)
     err = float(np.abs(got - want).max())
     worst = max(worst, err)
-    if not np.allclose(got, want, atol=3e-5, rtol=2e-5):
+    if not np.allclose(got, want, atol=ATOL, rtol=2e-5):
         print('MISMATCH case', case, (no, T, h, w), 'max err', err)
         sys.exit(1)
 print('ok: %d cases, worst abs error %.3g' % (cases, worst))

@@ -7,6 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from rmnet_amd import ops
 from oracle import oracle
+# RMNET_BANK_PRECISION=f16 runs the fp16-operand mode: its bar is 2^-10 of the largest value (tests/test_gpu_parity.py)
+ATOL = 5e-3 if os.environ.get('RMNET_BANK_PRECISION') == 'f16' else 3e-5
 dev = torch.device('cuda', 0)
 reads = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -38,7 +40,7 @@ for case, (no, T, h, w, seed) in enumerate([(2, 3, 6, 10, 5), (1, 5, 8, 8, 1), (
     bad = 0
     for r in range(n_here):
         got = bank.read(T, qk_d, qv_d, qr_d).cpu().numpy()
-        if not np.allclose(got, want, atol=3e-5, rtol=2e-5):
+        if not np.allclose(got, want, atol=ATOL, rtol=2e-5):
             bad += 1
     print('case %d %s: %d / %d reads wrong' % (case, (no, T, h, w), bad, n_here))
     bad_total += bad

@@ -1443,3 +1443,156 @@ def oracle_masked_mean(mv, mr):
             if x0 <= x1 and y0 <= y1:
                 m[o, 0, t, max(y0, 0):y1 + 1, max(x0, 0):x1 + 1] = 1
     return ((mv.astype(np.float64) * m).sum(axis=(2, 3, 4)) / (T * h * w)).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fp16-operand mode of the bank read (RMNET_BANK_F16 / RMNET_MR_F16): opt-in, about twice as fast, NOT fp32-class.
+# What it promises (include/rmnet_hip.h): K, V, q and the soft-max weights rounded to fp16 (11 significant bits), fp32
+# accumulate, the weights normalised by the sum of the ROUNDED weights.  The bars below are that arithmetic's, written
+# against the oracle (fp32 semantics): |error| <= 2^-10 of the largest |value| the read-out can average (4e-3 for
+# N(0,1) values; measured 3e-4 at worst, 5e-6 when hundreds of cells contribute), mean |error| < 1e-4.  What the
+# north star asks of it -- mask IoU within 1e-3 of the CPU path on whole clips -- is the second group of tests.
+F16_ATOL_REL = 2.0 ** -10
+
+
+def _f16_bars(got, want, vmax, smax=0.0):
+    """``smax`` = largest |logit| of the case: the rounding of K and q is relative, so a logit S is off by about
+    |S| * 2^-11 and the weights of two competing cells by that fraction -- the bar widens with max(1, smax / 8)."""
+    err = np.abs(got[:, :512] - want[:, :512])
+    wide = max(1.0, smax / 8.0)
+    assert not np.isnan(got).any()
+    assert float(err.max()) <= F16_ATOL_REL * vmax * wide, float(err.max())
+    assert float(err.mean()) < 1e-4 * wide, float(err.mean())
+    np.testing.assert_array_equal(got[:, 512:], want[:, 512:])      # the q_val half is a copy: exact in every mode
+
+
+@pytest.mark.parametrize('no,T,h,w,regional', [
+    (1, 1, 4, 5, False), (2, 3, 9, 13, True), (1, 5, 30, 54, True), (1, 7, 16, 24, False), (2, 9, 10, 7, True),
+    (14, 2, 6, 9, True), (70, 1, 4, 5, True), (5, 3, 30, 54, True), (5, 5, 30, 54, True), (3, 20, 12, 20, True),
+    (1, 70, 5, 6, True)])
+def test_bank_read_f16_mode_vs_oracle(no, T, h, w, regional, oracle_mod):
+    """Same cases as test_bank_read_vs_oracle (ragged boxes, empty boxes, > 12 and > 64 objects, odd tile counts --
+    a step of the fp16 loop is TWO tiles, which may belong to different frames), fp16-operand arithmetic."""
+    from rmnet_amd import ops
+    rng = np.random.RandomState(no * 1000 + T * 100 + h + 1)
+    mk, mv, qk, qv, mr, qr = _random_case(rng, no, T, h, w, regional=regional)
+    bank = ops.MemoryBank(no, T + 2, h, w, dev(), precision='f16')
+    for t in range(T):
+        bank.append(t, cu(mk[:, :, t]), cu(mv[:, :, t]), None if mr is None else cu(mr[:, t]))
+    if regional:
+        want, _ = oracle_mod.regional_memory_read(mk, mv, qk, qv, mr, qr)
+        got = bank.read(T, cu(qk), cu(qv), cu(qr)).cpu().numpy()
+        # cells outside the query box come from the column sums, not from the MFMAs: fp32-class in this mode too
+        inbox = np.zeros((no, 1, h, w), bool)
+        for o in range(no):
+            x0, x1, y0, y1 = qr[o]
+            inbox[o, 0, max(y0, 0):y1 + 1, max(x0, 0):x1 + 1] = x0 <= x1 and y0 <= y1
+        np.testing.assert_allclose((got[:, :512] * ~inbox), (want[:, :512] * ~inbox), atol=MR_ATOL, rtol=MR_RTOL)
+    else:
+        want, _ = oracle_mod.memory_read(mk, mv, qk, qv)
+        got = bank.read(T, cu(qk), cu(qv)).cpu().numpy()
+    _f16_bars(got, want, float(np.abs(mv).max()))
+    # the bank itself is mode-independent: the same bank read in the default mode meets the fp32-class bar
+    bank.precision = 'split'
+    got3 = bank.read(T, cu(qk), cu(qv), cu(qr) if regional else None).cpu().numpy()
+    np.testing.assert_allclose(got3, want, atol=MR_ATOL, rtol=MR_RTOL)
+
+
+def test_f16_mode_peaked_softmax_and_late_spike(oracle_mod):
+    """A soft-max dominated by one cell returns that cell's value with V's fp16 rounding only (the denominator is the
+    sum of the rounded weights); a late spike forces the deferred running maximum to bump in the middle of a step."""
+    from rmnet_amd import ops
+    rng = np.random.RandomState(5)
+    no, T, h, w = 2, 4, 8, 16
+    mk, mv, qk, qv, _, _ = _random_case(rng, no, T, h, w, regional=False)
+    mk[:, :, 3, h - 1, w - 2] = qk[:, :, 2, 3] * 9.0           # query cell (2,3) is dominated by memory cell (3, h-1, w-2)
+    # (logit ~ 36.  The rounding of K and q is RELATIVE, so a logit S carries an error of about |S| * 2^-11 * 0.3 and a
+    #  weight e^S that relative error: with logits in the hundreds two competing cells are mis-weighted by percents -- a
+    #  x40 spike here gives 7e-3.  That is the price of 11-bit operands and the reason the mode is opt-in.)
+    bank = ops.MemoryBank(no, T, h, w, dev(), precision='f16')
+    for t in range(T):
+        bank.append(t, cu(mk[:, :, t]), cu(mv[:, :, t]), None)
+    want, _ = oracle_mod.memory_read(mk, mv, qk, qv)
+    got = bank.read(T, cu(qk), cu(qv)).cpu().numpy()
+    _f16_bars(got, want, float(np.abs(mv).max()))
+    peak = np.abs(got[:, :512, 2, 3] - mv[:, :, 3, h - 1, w - 2])
+    assert float((peak / np.maximum(np.abs(mv[:, :, 3, h - 1, w - 2]), 2.0 ** -8)).max()) <= 2.0 ** -10   # V's rounding (2^-11) + a weight-sized rest
+
+
+def test_dropin_memory_read_f16_flag(golden_dir, oracle_mod):
+    """rmnet_memory_read_f32(..., RMNET_MR_F16): staging + fp16-operand read, dense and regional, on the reference's own
+    golden MemoryReader vectors and on a random case; the out-of-window fallback still goes to the exact kernel."""
+    from rmnet_amd import ops
+    g = np.load(os.path.join(golden_dir, 'memory_reader.npz'))
+    names = sorted({k.split('.')[0] for k in g.files})
+    checked = 0
+    for name in names:
+        if name + '.m_key' not in g.files or name + '.mem_val' not in g.files:
+            continue
+        mk, mv, qk, qv = (g[name + '.' + k].astype(np.float32) for k in ('m_key', 'm_val', 'q_key', 'q_val'))
+        if mk.shape[1] != 128 or mv.shape[1] != 512:
+            continue
+        got, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), flags=ops.MR_F16)
+        no_, _, T_, h_, w_ = mk.shape
+        smax = float(np.abs(np.einsum('ocj,oci->oji', mk.reshape(no_, 128, -1), qk.reshape(no_, 128, -1))).max()) / np.sqrt(128.0)
+        _f16_bars(got.cpu().numpy(), g[name + '.mem_val'].astype(np.float32), float(np.abs(mv).max()), smax)   # ("peaky": logits to 32)
+        checked += 1
+    assert checked >= 1
+    rng = np.random.RandomState(77)
+    mk, mv, qk, qv, mr, qr = _random_case(rng, 3, 4, 12, 20, regional=True)
+    want, _ = oracle_mod.regional_memory_read(mk, mv, qk, qv, mr, qr)
+    got, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), cu(mr), cu(qr), flags=ops.MR_F16)
+    _f16_bars(got.cpu().numpy(), want, float(np.abs(mv).max()))
+    mv2 = mv.copy()
+    mv2[1, 7, 2, 3, 4] = 5000.0                                  # outside the bank's window: the exact kernel answers
+    want2, _ = oracle_mod.regional_memory_read(mk, mv2, qk, qv, mr, qr)
+    got2, _ = ops.memory_read(cu(mk), cu(mv2), cu(qk), cu(qv), cu(mr), cu(qr), flags=ops.MR_F16)
+    np.testing.assert_allclose(got2.cpu().numpy(), want2, atol=MR_ATOL * 50, rtol=MR_RTOL)
+
+
+def test_f16_mode_whole_clip_meets_the_iou_bar(oracle_mod):
+    """The north star's correctness bar -- mask IoU within 1e-3 of the CPU path on identical inputs -- for the frame loop
+    with ``read_precision='f16'`` at the headline workload (480x854, 1 object, memory growing to T = 5) against
+    OracleRMNet, fused and un-fused; probabilities within 1e-3."""
+    from rmnet_amd import networks
+    from rmnet_amd.rmnet import RMNet
+    from rmnet_amd.synthetic import synthetic_clip
+    prod = networks.procedural_init_(RMNet(None, read_precision='f16'))
+    ref = oracle_mod.OracleRMNet()
+    ref.load_state_dict(prod.state_dict())
+    prod, ref = prod.to(dev()).eval(), ref.eval()
+    N, K, H, W = 6, 2, 480, 854
+    frames, masks, flows, n_objects = synthetic_clip(N, K, H, W, seed=11, size=1.3)
+    with torch.no_grad():
+        est_cpu = ref(frames, masks, flows, n_objects, 1)
+        est = prod(frames, masks, flows, n_objects, 1).cpu()
+        prod.fuse_epilogues()
+        est_f = prod(frames, masks, flows, n_objects, 1).cpu()
+    lab_cpu = est_cpu.argmax(2).numpy()
+    for e in (est, est_f):
+        assert float((e - est_cpu).abs().max()) < 1e-3
+        lab = e.argmax(2).numpy()
+        assert oracle_mod.iou(lab[:, 1:] == 1, lab_cpu[:, 1:] == 1) >= 0.999
+
+
+def test_f16_mode_multi_object_clips_against_the_default_mode(oracle_mod):
+    """Several objects, longer clips: the fp16-operand loop against the default (fp32-class) loop on the GPU, 20 frames.
+    With these procedural random weights the network amplifies a 1e-6 perturbation to a few 1e-3 of probability in a
+    handful of pixels (tools/dbg_loop5.py), so this is a statement about a chaotic map, not about trained weights:
+    per-object clip IoU >= 0.998 (measured 0.9985-0.99996; the default mode against the exact-fp32 read: >= 0.9998).
+    The reference task's bar of 1e-3 is met for one object (test above) and for three (0.9992); for five objects on
+    these weights it is not (0.9985), which is why the mode is opt-in."""
+    from rmnet_amd import networks
+    from rmnet_amd.rmnet import RMNet
+    from rmnet_amd.synthetic import synthetic_clip
+    prod = networks.procedural_init_(RMNet(None)).to(dev()).eval()
+    prod.fuse_epilogues()
+    for n_obj, every, seed, bar in [(3, 5, 3, 0.999), (5, 2, 4, 0.998)]:
+        frames, masks, flows, n_objects = synthetic_clip(20, n_obj + 1, 480, 854, seed=seed, size=1.1)
+        with torch.no_grad():
+            prod.read_precision = 'split'
+            a = prod(frames, masks, flows, n_objects, every).argmax(2).cpu().numpy()
+            prod.read_precision = 'f16'
+            b = prod(frames, masks, flows, n_objects, every).argmax(2).cpu().numpy()
+        for k in range(1, n_obj + 1):
+            assert oracle_mod.iou(a[:, 1:] == k, b[:, 1:] == k) >= bar, (n_obj, k)
