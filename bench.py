@@ -234,17 +234,24 @@ def kernel_figures(dev, events):
         for t in range(T):
             bank.append(t, k, v, r)
         e3 = (ev[2], ev[3], ev[4])
-        for _ in range(3):
-            bank.read(T, k, v, r)
-        torch.cuda.synchronize()
-        mm, cc = [], []
-        for _ in range(8):
-            bank.read(T, k, v, r, events=e3)
-            torch.cuda.synchronize()
-            mm.append(events.elapsed_ms(e3[0], e3[1]) * 1e3 - floor)
-            cc.append(events.elapsed_ms(e3[1], e3[2]) * 1e3 - floor)
         ab = algorithmic_bytes(no, T, h, w)
-        out[name] = gbs(ab, float(np.mean(mm) + max(np.mean(cc), 0.0)))     # (one kernel = the whole op)
+        for mode in ('split', 'f16'):
+            bank.precision = mode
+            for _ in range(3):
+                bank.read(T, k, v, r)
+            torch.cuda.synchronize()
+            mm, cc = [], []
+            for _ in range(8):
+                bank.read(T, k, v, r, events=e3)
+                torch.cuda.synchronize()
+                mm.append(events.elapsed_ms(e3[0], e3[1]) * 1e3 - floor)
+                cc.append(events.elapsed_ms(e3[1], e3[2]) * 1e3 - floor)
+            row = gbs(ab, float(np.mean(mm) + max(np.mean(cc), 0.0)))       # (one kernel = the whole op)
+            if mode == 'split':
+                out[name] = row
+            else:
+                out[name]['f16_mode'] = {'us': row['us'], 'GBps': row['GBps'], 'hbm_frac': row['hbm_frac']}
+        bank.precision = 'split'
         if name.startswith('cfg3'):
             out['bk_append_5obj_480p'] = gbs(2 * 4 * (DE + DO) * h * w * no, bracket(lambda: bank.append(T - 1, k, v, r)))
         del bank
@@ -319,6 +326,10 @@ def main():
                     help='independent clips batched on every GPU (one 480p clip cannot fill 256 CUs; measured '
                          'on MI355X: 164 / 194 / 227 / 248 / 247 frames/s at 1 / 2 / 4 / 8 / 10 clips)')
     ap.add_argument('--graph', action='store_true', help='replay the frame step as one captured HIP graph')
+    ap.add_argument('--read-precision', choices=('split', 'f16'), default='split',
+                    help="arithmetic of the bank read in the timed region: 'split' = fp16 hi/lo pairs, three MFMA terms, fp32-class "
+                         "(default); 'f16' = fp16 operands, one term, ~2^-11 relative (opt-in mode, include/rmnet_hip.h).  The other "
+                         "mode's kernel is timed on the same launches after the timed region and reported under roofline.modes")
     ap.add_argument('--dist-backend', default=None, help="override the process-group backend ('gloo' lets several "
                     "ranks share one GPU when testing the N>1 path on a 1-GPU box)")
     args = ap.parse_args()
@@ -339,7 +350,7 @@ def main():
     torch.set_grad_enabled(False)
     torch.backends.cudnn.benchmark = not args.no_miopen_find
 
-    net = networks.procedural_init_(RMNet(None)).to(dev).eval()
+    net = networks.procedural_init_(RMNet(None, read_precision=args.read_precision)).to(dev).eval()
     tfn = networks.procedural_init_(TinyFlowNet(None)).to(dev).eval()
     if args.fold_bn:
         net.fuse_for_inference()
@@ -430,6 +441,19 @@ def main():
 
     main_ms = [events.elapsed_ms(events.ev[3 * i], events.ev[3 * i + 1]) for i in range(args.steps)]
     comb_ms = [events.elapsed_ms(events.ev[3 * i + 1], events.ev[3 * i + 2]) for i in range(args.steps)]
+    # the OTHER arithmetic mode of the same kernel on the same launches (same bank, same boxes), outside the timed region
+    other_mode = 'f16' if args.read_precision == 'split' else 'split'
+    other_ms = None
+    if not args.no_extras:
+        bank.precision = other_mode
+        for i in range(3):
+            eager_step(i)
+        for i in range(args.steps):
+            eager_step(i, tuple(events.ev[3 * i:3 * i + 3]))
+        torch.cuda.synchronize()
+        net._profile_events = None
+        bank.precision = args.read_precision
+        other_ms = [events.elapsed_ms(events.ev[3 * i], events.ev[3 * i + 2]) - 2e-3 * ev_floor_us for i in range(args.steps)]
     main_raw = sum(main_ms) / len(main_ms)
     main_avg = max(main_raw - ev_floor_us * 1e-3, 1e-6)     # kernel time = bracket - empty-bracket floor
     abytes = algorithmic_bytes(B * (K_CH - 1), T_MEM, ctx.h, ctx.w)
@@ -445,22 +469,24 @@ def main():
     qr = qr[:, 1].cpu()
     mq = (qr[:, 1] - qr[:, 0] + 1).clamp(min=0) * (qr[:, 3] - qr[:, 2] + 1).clamp(min=0)
     nqt = (mq + 63) // 64
-    mfma_flops = float((nqt * 64 * njt * 32).sum()) * (DE + DO) * 2 * 3          # executed: 3 split terms over the padded tiles
+    n_terms = 3 if args.read_precision == 'split' else 1
+    mfma_flops = float((nqt * 64 * njt * 32).sum()) * (DE + DO) * 2 * n_terms    # executed: the mode's MFMA terms over the padded tiles
     mfma_tflops = mfma_flops / (main_avg * 1e-3) / 1e12
     useful_flops = float((mq * areas.sum(dim=1)).sum()) * (DE + DO) * 2          # one term over the un-padded regional cells
     useful_tflops = useful_flops / (main_avg * 1e-3) / 1e12
     comb_avg = max(sum(comb_ms) / len(comb_ms) - ev_floor_us * 1e-3, 1e-6)
     op_achieved = abytes / ((main_avg + comb_avg) * 1e-3) / 1e9
     traffic, traffic_note = None, 'no PMC file for this kernel version'
-    tpath = os.path.join(ROOT, 'profiles', 'bk_main_hbm_traffic.json')   # from separate --pmc passes (tools/pmc_traffic.sh)
+    tname = 'bk_main_hbm_traffic.json' if args.read_precision == 'split' else 'bk_main_f16_hbm_traffic.json'
+    tpath = os.path.join(ROOT, 'profiles', tname)                        # from separate --pmc passes (tools/pmc_traffic.sh)
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         if tj.get('source_hash') == source_hash() and int(tj.get('algorithmic_bytes_per_launch', -1)) == int(abytes):
             traffic = tj.get('hbm_bytes_per_launch')
-            traffic_note = ('profiles/bk_main_hbm_traffic.json (same kernel sources, same workload): FETCH_SIZE x 2 + WRITE_SIZE x 1, the '
+            traffic_note = ('profiles/' + tname + ' (same kernel sources, same workload): FETCH_SIZE x 2 + WRITE_SIZE x 1, the '
                             'factors calibrated on known byte counts in profiles/r03_power_ceiling.md')
         else:
-            traffic_note = 'profiles/bk_main_hbm_traffic.json is from other kernel sources or another workload: not reported'
+            traffic_note = 'profiles/' + tname + ' is from other kernel sources or another workload: not reported'
 
     extras = None
     if rank == 0 and world == 1 and not args.no_extras:
@@ -536,14 +562,30 @@ def main():
         est_g = net(ff, fm, tfn(ff), fn_obj, 5, graph=True)                  # RMNet.forward's default for clips >= 8 frames
         torch.cuda.synchronize()
         dt_free_g = time.perf_counter() - t1
+        saved_prec = net.read_precision
+        net.read_precision = 'f16' if saved_prec == 'split' else 'split'
+        net(ff[:, :6], fm[:, :6], tfn(ff[:, :6]), fn_obj[:, :6], 5)          # warm-up
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        est_o = net(ff, fm, tfn(ff), fn_obj, 5, graph=False)
+        torch.cuda.synchronize()
+        dt_free_o = time.perf_counter() - t1
+        net.read_precision = saved_prec
+        la_, lb_ = est.argmax(2), est_o.argmax(2)
+        inter = float(((la_ == 1) & (lb_ == 1)).sum())
+        union = float(((la_ == 1) | (lb_ == 1)).sum())
         cover = float((est[0, 1:, 1] > 0.5).float().mean())
         extras['free_running'] = {'fps': round((N_FREE - 1) / dt_free, 2), 'fps_graph': round((N_FREE - 1) / dt_free_g, 2),
                                   'graph_vs_eager_max_prob_diff': round(float((est - est_g).abs().max()), 6),
+                                  'f16_vs_split': {'fps_other_mode': round((N_FREE - 1) / dt_free_o, 2),
+                                                   'label_iou': round(inter / union, 6) if union else 1.0,
+                                                   'max_prob_diff': round(float((est - est_o).abs().max()), 6),
+                                                   'note': 'the same clip through both arithmetic modes of the bank read (masks fed back for 66 frames)'},
                                   'frames': N_FREE, 'memorize_every': 5,
                                   'memory_frames_at_end': 14, 'clips': 1,
                                   'note': 'RMNet.forward + TinyFlowNet on one clip, masks fed back; with random-init weights the '
                                           'estimated object covers %.0f %% of the frame on average (boxes follow it)' % (100 * cover)}
-        del ff, est, est_g
+        del ff, est, est_g, est_o
         # ---- whole-loop frames/s at the other BASELINE configurations: same step as the headline, other shapes
         extras['loops'] = {
             'cfg2_5obj_T5_480p_1clip': loop_fps(net, tfn, dev, 1, 6, 5, H, W, 5, 10),
@@ -561,7 +603,9 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32 (convs fp32; memory read = split-fp16 MFMA hi*hi+hi*lo+lo*hi with fp32 accumulate, fp32-class accuracy)',
+            'dtype': ('f32 (convs fp32; memory read = split-fp16 MFMA hi*hi+hi*lo+lo*hi with fp32 accumulate, fp32-class accuracy)'
+                      if args.read_precision == 'split' else
+                      'f32 convs; memory read = fp16 operands (K, V, q, P rounded to 11 bits), fp32 accumulate: the opt-in RMNET_BANK_F16 mode'),
             'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: 480x854 synthetic clips, 1 object each (K=2), memory pinned '
                                    'at T=5, TinyFlowNet + memorize + regional read + decoder per frame; '
@@ -575,17 +619,19 @@ def main():
                        'batchnorm_folded': bool(args.fold_bn),
                        'fused_epilogues': bool(not args.fold_bn and not args.no_fuse_epilogue and not args.channels_last)},
             'roofline': {'bound': 'mfma',
-                         'kernel': 'bk_main = the whole regional memory read in ONE launch (split-fp16 MFMA read of the bank, merge of the '
-                                   'partial results by the last workgroup of every query tile, masked cells, q_val half of the cat)',
+                         'kernel': 'bk_main<%d> = the whole regional memory read in ONE launch (%s MFMA read of the bank, merge of the '
+                                   'partial results by the last workgroup of every query tile, masked cells, q_val half of the cat)'
+                                   % (n_terms, 'split-fp16 (3-term)' if n_terms == 3 else 'fp16-operand (1-term)'),
+                         'read_precision': args.read_precision,
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                          'definition': 'SURVEY.md 8d / BASELINE.json: algorithmic bytes per launch (%d B = %d object-frames x 31,518,720 B) / '
                                        'mean kernel duration, against 8 TB/s HBM' % (abytes, B * (K_CH - 1)),
                          'traffic': traffic, 'traffic_source': traffic_note,
                          'algorithmic_bytes_per_launch': abytes,
-                         'mfma': {'executed_3term_tflops': round(mfma_tflops, 1), 'useful_1term_tflops': round(useful_tflops, 1),
+                         'mfma': {'executed_%dterm_tflops' % n_terms: round(mfma_tflops, 1), 'useful_1term_tflops': round(useful_tflops, 1),
                                   'dense_1term_tflops': round(B * (K_CH - 1) * 2.0 * T_MEM * ctx.h * ctx.w * ctx.h * ctx.w * (DE + DO) / (main_avg * 1e-3) / 1e12, 1),
                                   'peak': 2500.0, 'unit': 'TFLOP/s', 'executed_frac_of_peak': round(mfma_tflops / 2500.0, 4),
-                                  'note': 'executed = 3 split-fp16 terms (hi*hi + hi*lo + lo*hi) over the compacted 64-query x 32-cell tiles incl. '
+                                  'note': 'executed = the MFMA terms of the mode (split: hi*hi + hi*lo + lo*hi; f16: one) over the compacted 64-query x 32-cell tiles incl. '
                                           'padding; useful = one term over the un-padded regional cells; dense = SURVEY 8d '
                                           '2*THW*hw*(De+Do) per object-frame as if nothing were masked.  The kernel is power-capped on the '
                                           'matrix pipe (profiles/r03_power_ceiling.md): a pure random-data MFMA loop sustains 1.7-1.9 PFLOP/s'},
@@ -597,6 +643,17 @@ def main():
                                    'minus the empty-bracket floor measured the same way (op_* adds the now empty second bracket where '
                                    'round 2 had its combine kernel)'},
         }
+        if other_ms is not None:
+            o_us = 1e3 * sum(other_ms) / len(other_ms)
+            this = {'avg_us': round((main_avg + comb_avg) * 1e3, 2), 'GBps': round(op_achieved, 1), 'frac': round(op_achieved / HBM_PEAK_GBS, 4)}
+            other = {'avg_us': round(o_us, 2), 'GBps': round(abytes / o_us / 1e3, 1), 'frac': round(abytes / o_us / 1e3 / HBM_PEAK_GBS, 4)}
+            line['roofline']['modes'] = {
+                args.read_precision: this, other_mode: other,
+                'note': "the same launches (same bank, same boxes) in both arithmetic modes of the kernel, whole read, HIP events on the "
+                        "launch stream; the top-level figures are the timed region's mode ('%s').  split = default, fp32-class (error 1e-7); "
+                        "f16 = opt-in RMNET_BANK_F16: fp16 operands, fp32 accumulate, read-out error ~2^-11 of the values (3e-4 worst, 5e-6 "
+                        "typical), whole-clip mask IoU vs the CPU path 1.0000 for this workload, >= 0.9985 for 3-5 objects on random-init "
+                        "weights (tests/test_gpu_parity.py, extras.free_running.f16_vs_split)" % args.read_precision}
         if extras is not None:
             line['extras'] = extras
         if world == 1 and not args.no_cpu_baseline:

@@ -1168,6 +1168,10 @@ constexpr int kStaticRowsPerTicket = BK_STATIC_ROWS;            // (object, chan
 #define BK_STATIC_BPUS 35.0e3f
 #endif
 constexpr float kStaticBytesPerUs = BK_STATIC_BPUS;             // what one streaming workgroup moves (sizing of the set-aside)
+#ifndef BK_STATIC_BPUS_F16
+#define BK_STATIC_BPUS_F16 50.0e3f                              // fp16 mode: fewer set aside (measured 25 / 35 / 50 / 70 / 100e3: 69.2 / 69.7 / 65.7 / 67.3 / 68.7 us)
+#endif
+constexpr float kStaticBytesPerUsF16 = BK_STATIC_BPUS_F16;
 constexpr float kTileUs = 1.75f, kTileUsF16 = 0.55f, kLaunchUs = 12.0f;   // tile step / fixed part of a compute workgroup (same estimate)
 static_assert(kSplitMax * kQT * 4 <= 2 * kPbuf, "merge weights live in the P buffers");
 static_assert(kConsumers * 16 * 65 * 4 + 2 * 4 * kQT * 4 <= 8 * kKbuf, "epilogue scratch lives in the K ring");
@@ -1264,7 +1268,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     if (!(BK_ABLATE & 256)) {
       const float static_bytes = (float)ng * (float)hw * (float)kDo * 4.0f * 2.5f;
       const float compute_us = kLaunchUs + (kTerms == 1 ? kTileUsF16 : kTileUs) * (float)W / (float)a.target;
-      int aside = (int)(static_bytes / (compute_us * kStaticBytesPerUs) + 0.5f);
+      int aside = (int)(static_bytes / (compute_us * (kTerms == 1 ? kStaticBytesPerUsF16 : kStaticBytesPerUs)) + 0.5f);
       aside = min(aside, a.target / 4);
       target = a.target - aside;
     }

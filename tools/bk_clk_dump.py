@@ -16,6 +16,14 @@ qk = (torch.randn(no, 128, h, w, generator=g) * 0.6).to(dev)
 qv = torch.randn(no, 512, h, w, generator=g).to(dev)
 qr = torch.tensor([(2, 2 + qw - 1, 1, 1 + qh - 1)] * no, dtype=torch.int32, device=dev)
 mr = torch.tensor([(3, 3 + mw - 1, 2, 2 + mh - 1)] * no, dtype=torch.int32, device=dev)
+if qh == 0:        # per-object random boxes as bench.py's clips have them (tools/comb_bench.py), the same box for memory and query
+    rng = np.random.RandomState(1)
+    rects = []
+    for o in range(no):
+        rh, rw = rng.randint(17, 24), rng.randint(32, 42)
+        y0, x0 = rng.randint(0, h - rh + 1), rng.randint(0, w - rw + 1)
+        rects.append((x0, x0 + rw - 1, y0, y0 + rh - 1))
+    qr = mr = torch.tensor(rects, dtype=torch.int32, device=dev)
 bank = ops.MemoryBank(no, T, h, w, dev, precision=os.environ.get('RMNET_BANK_PRECISION', 'split'))
 for t in range(T):
     bank.append(t, mk[:, :, t].contiguous(), mv[:, :, t].contiguous(), mr)

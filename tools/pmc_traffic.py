@@ -47,9 +47,10 @@ def main():
         import bench
         H, W, K, T = bench.H, bench.W, bench.K_CH, bench.T_MEM
         abytes = bench.algorithmic_bytes(8 * (K - 1), T, 30, 54)
-        prof = {'kernel': 'bk_main', 'source_hash': bench.source_hash(),
+        prec = 'f16' if sys.argv[-1] == 'f16' else 'split'
+        prof = {'kernel': 'bk_main<%d>' % (1 if prec == 'f16' else 3), 'read_precision': prec, 'source_hash': bench.source_hash(),
                 'command': 'tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE (then WRITE_SIZE, separate pass) --kernel-trace -- '
-                           'python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extras (8 object-frames per launch)',
+                           'python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extras --read-precision %s (8 object-frames per launch)' % prec,
                 'fetch_size_kb_per_launch': round(fetch['bk_main'][0], 1), 'write_size_kb_per_launch': round(write['bk_main'][0], 1),
                 'hbm_bytes_per_launch': int(1024 * (FETCH_FACTOR * fetch['bk_main'][0] + WRITE_FACTOR * write['bk_main'][0])),
                 'fetch_factor': FETCH_FACTOR, 'write_factor': WRITE_FACTOR,
@@ -58,8 +59,9 @@ def main():
                 'other_kernels_same_run': {k: {'fetch_size_kb_per_launch': round(fetch.get(k, (0, 0))[0], 1),
                                                'write_size_kb_per_launch': round(write.get(k, (0, 0))[0], 1)}
                                            for k in sorted(set(fetch) | set(write)) if k != 'bk_main'}}
-        json.dump(prof, open(os.path.join(ROOT, 'profiles', 'bk_main_hbm_traffic.json'), 'w'), indent=1)
-        print('wrote profiles/bk_main_hbm_traffic.json')
+        fname = 'bk_main_f16_hbm_traffic.json' if prec == 'f16' else 'bk_main_hbm_traffic.json'
+        json.dump(prof, open(os.path.join(ROOT, 'profiles', fname), 'w'), indent=1)
+        print('wrote profiles/' + fname)
 
 
 if __name__ == '__main__':

@@ -7,13 +7,17 @@ set -e
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 ROOT=$PWD
 export TMPDIR=/tmp
-mkdir -p gpurun_out/pmc
+# PRECISION=f16 bash tools/pmc_traffic.sh does the same for the fp16-operand mode -> gpurun_out/pmc_f16/, profiles/bk_main_f16_hbm_traffic.json
+PREC=${PRECISION:-split}
+out=gpurun_out/pmc; [ "$PREC" = f16 ] && out=gpurun_out/pmc_f16
+mkdir -p $out
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extras > /tmp/pmc_$c.log 2>&1 || true
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extras --read-precision $PREC > /tmp/pmc_$c.log 2>&1 || true
   f=$(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1)
-  grep -E "bk_main|mr_combine|bk_append|region_reduce|region_fill|flow_affine|soft_aggregate" "$f" > $ROOT/gpurun_out/pmc/$c.csv || true
+  grep -E "bk_main|mr_combine|bk_append|region_reduce|region_fill|flow_affine|soft_aggregate" "$f" > $ROOT/$out/$c.csv || true
   tail -1 /tmp/pmc_$c.log | cut -c1-300
 done
-python $ROOT/tools/pmc_traffic.py $ROOT/gpurun_out/pmc --write-profile && cp $ROOT/profiles/bk_main_hbm_traffic.json $ROOT/gpurun_out/pmc/
+name=bk_main_hbm_traffic.json; [ "$PREC" = f16 ] && name=bk_main_f16_hbm_traffic.json
+python $ROOT/tools/pmc_traffic.py $ROOT/$out --write-profile $PREC && cp $ROOT/profiles/$name $ROOT/$out/

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Raw evidence for DESIGN.md section 5 ("what bounds bk_main"): socket power under load, in-kernel shader clock,
 # the pure-MFMA ceiling on zero / random operands, and the energy-share table from ablated builds.
-# Needs build/variants/lib_{clk,a1,a2,a4,a16,a256,a1024}.so (tools/build_variant.sh <name> -DBK_CLK=1 -DBK_ABLATE=<mask>)
+# Needs build/variants/lib_{clk,a1,a2,a4,a16,a17,a256,a1024,f16a1,...,f16tr,f16tr8}.so (tools/build_variants_all.sh)
 # and tools/ubench/mfma_power.
 # Output: gpurun_out/r03_power/raw.txt (copied, with the command lines, into profiles/r03_power_ceiling.md).
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
@@ -33,5 +33,24 @@ for v in clk a1 a2 a4 a16 a17 a256 a1024; do
   RMNET_HIP_LIB=build/variants/lib_$v.so python tools/chunk_bench.py $W 2>&1 | tail -1
   RMNET_HIP_LIB=build/variants/lib_$v.so python tools/bk_clk.py $W 2>&1 | tail -1
 done
+echo
+echo "### fp16-operand mode (RMNET_BANK_PRECISION=f16 -> RMNET_BANK_F16): the same launch and a launch with per-object random boxes as bench.py's"
+echo "### clips have them; ablations of the fp16 loops (BK_ABLATE: 1 no V loads, 2 no PV MFMAs, 4 no S / soft-max, 16 no K ring, 17 = 1 + 16,"
+echo "### 32 P fragments read once, 256 no static part); per-phase cycle stamps (-DBK_TRACE=1: producer wave 0 / consumer wave 4, wave 8)"
+export RMNET_BANK_PRECISION=f16
+for WW in "$W" "8 0 0 0 0 5"; do
+  for v in clk f16a1 f16a2 f16a4 f16a16 f16a17 f16a32 f16a256; do
+    [ -f build/variants/lib_$v.so ] || continue
+    echo "### \$ RMNET_BANK_PRECISION=f16 RMNET_HIP_LIB=build/variants/lib_$v.so python tools/chunk_bench.py $WW ; ... bk_clk.py $WW"
+    RMNET_HIP_LIB=build/variants/lib_$v.so python tools/chunk_bench.py $WW 2>&1 | tail -1
+    RMNET_HIP_LIB=build/variants/lib_$v.so python tools/bk_clk.py $WW 2>&1 | tail -1
+  done
+done
+for v in f16tr f16tr8; do
+  [ -f build/variants/lib_$v.so ] || continue
+  echo "### \$ RMNET_BANK_PRECISION=f16 RMNET_HIP_LIB=build/variants/lib_$v.so python tools/bk_trace.py 0.46 40"
+  RMNET_HIP_LIB=build/variants/lib_$v.so python tools/bk_trace.py 0.46 40 2>&1 | grep -v amdgpu.ids | tail -10
+done
+unset RMNET_BANK_PRECISION
 } > $out/raw.txt 2>&1
 tail -40 $out/raw.txt
