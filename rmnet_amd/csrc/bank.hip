@@ -339,9 +339,6 @@ constexpr int kRThreads = 64 * (kProducers + kConsumers);  // 768 = 12 waves = 3
 #ifndef BK_VNT
 #define BK_VNT 0       // experiments only: non-temporal V fragment loads
 #endif
-#ifndef BK_SPLIT_DEEP
-#define BK_SPLIT_DEEP 0 // split mode (experiment): 1 = the fp16 mode's pipeline depth (producers one more tile ahead, P triple-buffered,
-#endif                  //                          the consumers' P fragments requested before the barrier)
 #ifndef BK_F16_FRAGS
 #define BK_F16_FRAGS 0 // fp16 mode, producers (experiment): 1 = the next K fragments are requested behind the S MFMAs (measured: no gain), 0 = after the soft-max
 #endif
@@ -598,51 +595,6 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
   f32x4 sp0, sp1;                  // S of the tile after it (computed one iteration earlier)
   Frags f;
   __syncthreads();                                   // A: K tiles 0..3 in LDS
-#if BK_SPLIT_DEEP
-  {
-    f32x4 s0, s1, t0, t1;
-    k_frags(f, 0);
-    s_mfma(f, s0, s1);
-    k_frags(f, 1);
-    s_mfma(f, t0, t1);
-    k_frags(f, 2);
-    s_mfma(f, sp0, sp1);
-    const int l0 = cs.seek(jt0);
-    soft_max(s0, s1, tarea[cs.tt] - l0 * kJT, 0);
-    const int l1 = cs.seek(jt0 + 1);
-    soft_max(t0, t1, 1 < ntl ? tarea[cs.tt] - l1 * kJT : 0, 1);
-    k_frags(f, 3);
-  }
-  __syncthreads();                                   // B: P(0), P(1) visible; ring slot 0 read
-  {
-    k_store(kr, 0);                                  // tile 4
-    const int l5 = ck.seek(jt0 + 5);
-    k_load(kr, ck.tt, l5);
-  }
-  __syncthreads();                                   // C: tile 4 in slot 0
-  BK_STAMP();
-  int pbuf = 2;
-  for (int n = 0; n < ntl; ++n) {
-    BK_STAMP();   // loop top
-    const int l2 = cs.seek(jt0 + n + 2);
-    const int nvalid = n + 2 < ntl ? tarea[cs.tt] - l2 * kJT : 0;
-    f32x4 s0, s1;
-    s_mfma(f, s0, s1);                               // tile n+3
-    __builtin_amdgcn_sched_barrier(0);
-    BK_STAMP();   // MFMAs issued
-    soft_max(sp0, sp1, nvalid, pbuf);                // tile n+2
-    BK_STAMP();   // soft-max done
-    sp0 = s0; sp1 = s1;
-    k_frags(f, n & 3);                               // tile n+4
-    k_store(kr, (n + 1) & 3);                        // tile n+5 (its slot was last read in iteration n-3)
-    const int l6 = ck.seek(jt0 + n + 6);
-    k_load(kr, ck.tt, l6);
-    pbuf = pbuf == 2 ? 0 : pbuf + 1;
-    BK_STAMP();   // S/soft-max done
-    __syncthreads();
-    BK_STAMP();   // after barrier
-  }
-#else
   if (!(BK_ABLATE & 4)) {
     f32x4 s0, s1;
     k_frags(f, 0);
@@ -688,7 +640,6 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
     __syncthreads();
     BK_STAMP();   // after barrier
   }
-#endif
   m_out = mref * kSraw;                                // log2 domain; the segment's epilogue takes it from here
   l_out = lsum;
   BK_STAMP();
@@ -741,28 +692,11 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
     for (int it = 0; it < 4; ++it) acc[dt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();                                   // A: K tiles 0..3 visible
   __syncthreads();                                   // B: P(0) visible
-#if BK_SPLIT_DEEP
-  half8 bh[4], bl[4];                                // P fragments of the current tile: requested an iteration early
-  f32x4 al;
-  auto p_frags = [&](int buf) {
-    const char* pfr = Pl_ + buf * kPbuf;
-    al = *reinterpret_cast<const f32x4*>(Al + buf * kQT + l15 * 4);
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      bh[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + lane * 16);
-      bl[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + 1024 + lane * 16);
-    }
-  };
-  p_frags(0);
-  int pnext = 1;
-  __syncthreads();                                   // C
-#endif
   BK_STAMP();
 
   for (int n = 0; n < ntl; ++n) {
-    BK_STAMP();   // loop top
-#if !BK_SPLIT_DEEP
     const int buf = n & 1;
+    BK_STAMP();   // loop top
     const char* pfr = Pl_ + buf * kPbuf;
     const f32x4 al = *reinterpret_cast<const f32x4*>(Al + buf * kQT + l15 * 4);
     half8 bh[4], bl[4];                              // all P fragments of this tile
@@ -771,7 +705,6 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
       bh[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + lane * 16);
       bl[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + 1024 + lane * 16);
     }
-#endif
     const int l1 = cv.seek(jt0 + n + 1);             // refill source: tile n+1 (clamped past the end)
     const size_t noff = v_tile(cv.tt, l1);
     const char* nvh = b.vh + noff;
@@ -814,10 +747,6 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
       BK_STAMP();   // channel tile done
 #endif
     }
-#if BK_SPLIT_DEEP
-    p_frags(pnext);                                  // tile n+1: published an iteration ago; lands under the barrier
-    pnext = pnext == 2 ? 0 : pnext + 1;
-#endif
     BK_STAMP();   // PV done
 #if BK_ABLATE & 128
     if (n & 1)
