@@ -339,12 +339,6 @@ constexpr int kRThreads = 64 * (kProducers + kConsumers);  // 768 = 12 waves = 3
 #ifndef BK_VNT
 #define BK_VNT 0       // experiments only: non-temporal V fragment loads
 #endif
-#ifndef BK_F16_FRAGS
-#define BK_F16_FRAGS 0 // fp16 mode, producers (experiment): 1 = the next K fragments are requested behind the S MFMAs (measured: no gain), 0 = after the soft-max
-#endif
-#ifndef BK_F16_V
-#define BK_F16_V 0     // fp16 mode, consumers (experiments): 1 K ring mid-step, 2 a V load after every 4 MFMAs
-#endif
 #ifndef BK_F16_INTERLEAVE
 #define BK_F16_INTERLEAVE 6   // fp16 mode, producers: soft-max VALU instructions scheduled between two S MFMAs (0 = as the compiler likes)
 #endif
@@ -928,29 +922,21 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
     s0 = sp;
 #else
     s_mfma(f, s0);                                   // step n+3
-#if !(BK_ABLATE & 64) && (BK_F16_FRAGS == 1)
-    k_frags(f, n & 3);                               // step n+4: each fragment is requested right behind the MFMA that read
-                                                     // its register, so the 16 KB land under the soft-max, not in front of the barrier
-#endif
     soft_max(sp, pbuf);                              // step n+2
 #endif
-    // one S MFMA, its fragment's refill, then a few soft-max VALU instructions, and so on: issued back to back the 16
-    // MFMAs of this wave wait for the pipe behind the consumers' (~40 cycles each, trace) while its VALU chain sits
-    // behind them in program order
+    // one S MFMA, then a few soft-max VALU instructions, and so on: issued back to back the 16 MFMAs of this wave wait
+    // for the pipe behind the consumers' (~40 cycles each, trace) while its VALU chain sits behind them in program order
 #if BK_F16_INTERLEAVE
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#if BK_F16_FRAGS == 1
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#endif
       __builtin_amdgcn_sched_group_barrier(0x002, BK_F16_INTERLEAVE, 0);
     }
 #endif
     __builtin_amdgcn_sched_barrier(0);
     BK_STAMP();   // S MFMAs + soft-max done
     sp = s0;
-#if !(BK_ABLATE & 64) && (BK_F16_FRAGS != 1)
+#if !(BK_ABLATE & 64)
     k_frags(f, n & 3);                               // step n+4
 #endif
     step_valid(n + 3, nva, nvb);                     // (LDS round trips: they end under the barrier)
@@ -1064,7 +1050,7 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
   v_next(1);
   for (int n = 0; n < nst; ++n) {
     BK_STAMP();   // loop top
-#if !(BK_F16_V & 1) && !(BK_ABLATE & 16)
+#if !(BK_ABLATE & 16)
     k_store(kr, (n + 1) & 3);                        // step n+5 (its slot was last read in iteration n-3)
     k_load(kr, n + 6);
 #endif
@@ -1076,19 +1062,10 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
     }
 #pragma unroll
     for (int dt = 0; dt < kCDT; ++dt) {
-#if BK_F16_V & 4
-      // the two consumers of a SIMD take turns at the matrix pipe (the arbiter prefers the older wave: the younger
-      // one would finish every step last)
-      if (((dt ^ (wave >> 3)) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#endif
 #if !(BK_ABLATE & 2)
 #pragma unroll
       for (int it = 0; it < 4; ++it)
         acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va[dt], pa[it], acc[dt][it], 0, 0, 0);
-#endif
-#if BK_F16_V & 2
-      va[dt] = *reinterpret_cast<const half8*>(nva + dt * 1024);
-      __builtin_amdgcn_sched_barrier(0);
 #endif
 #if !(BK_ABLATE & 2)
 #pragma unroll
@@ -1096,19 +1073,10 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
         acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[dt], pb[it], acc[dt][it], 0, 0, 0);
 #endif
 #if !(BK_ABLATE & 1)
-#if !(BK_F16_V & 2)
       va[dt] = *reinterpret_cast<const half8*>(nva + dt * 1024);
-#endif
       vb[dt] = *reinterpret_cast<const half8*>(nvb + dt * 1024);
 #endif
       __builtin_amdgcn_sched_barrier(0);
-#if BK_F16_V & 1
-      if (dt == 1) {                                 // the K ring in the middle of the step, not in everybody's first cycles
-        k_store(kr, (n + 1) & 3);                    // step n+5 (its slot was last read in iteration n-3)
-        k_load(kr, n + 6);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#endif
     }
 #if BK_ABLATE & 32
     if (n == 0)   // (experiment, wrong results: the P fragments are read once per segment)
