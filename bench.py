@@ -559,7 +559,7 @@ def main():
         torch.cuda.synchronize()
         dt_free = time.perf_counter() - t1
         t1 = time.perf_counter()
-        est_g = net(ff, fm, tfn(ff), fn_obj, 5, graph=True)                  # RMNet.forward's default for clips >= 8 frames
+        est_g = net(ff, fm, tfn(ff), fn_obj, 5, graph=True)                  # opt-in graph replay (RMNet.forward's default is eager)
         torch.cuda.synchronize()
         dt_free_g = time.perf_counter() - t1
         saved_prec = net.read_precision

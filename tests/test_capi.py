@@ -76,3 +76,25 @@ def test_ops_reject_cpu_tensors_like_the_reference():
         ops.soft_aggregate(torch.zeros(1, 2, 16, 16), torch.zeros(2, dtype=torch.int32), 2, (0, 0, 0, 0))
     with pytest.raises(RuntimeError, match='CUDA'):
         ops.region_map(torch.zeros(1, 2, 8, 8), flow=torch.zeros(1, 2, 8, 8))
+
+
+def test_flag_constants_of_the_python_mirror_match_the_header():
+    """ops.MR_* / ops.BANK_* are the header's RMNET_MR_* / RMNET_BANK_* (ABI v3 added the fp16-operand switch), and the
+    precision knob of the mirror only takes the two documented values."""
+    from rmnet_amd import _lib, ops
+    from rmnet_amd.rmnet import MemoryReader, RMNet
+    src = open(os.path.join(ROOT, 'include', 'rmnet_hip.h')).read()
+    defs = {m.group(1): int(m.group(2)) for m in re.finditer(r'^#define\s+(RMNET_\w+)\s+(-?\d+)\b', src, re.M)}
+    assert defs['RMNET_ABI_VERSION'] == _lib.ABI_VERSION == 3
+    assert defs['RMNET_MR_FORCE_GENERIC'] == ops.MR_FORCE_GENERIC and defs['RMNET_MR_EXACT_FP32'] == ops.MR_EXACT_FP32
+    assert defs['RMNET_MR_F16'] == ops.MR_F16 == defs['RMNET_BANK_F16'] == ops.BANK_F16
+    assert len({defs['RMNET_MR_FORCE_GENERIC'], defs['RMNET_MR_EXACT_FP32'], defs['RMNET_MR_F16']}) == 3   # distinct bits
+    assert ops._precision('split') == 'split' and ops._precision('f16') == 'f16'
+    with pytest.raises(ValueError):
+        ops._precision('bf16')
+    with pytest.raises(ValueError):
+        RMNet(None, read_precision='fp8')
+    assert RMNet(None).read_precision == 'split' and MemoryReader().precision == 'split'      # fp32-class unless asked
+    lib = _lib.load()
+    # the fp16 switch is the only flag rmnet_bank_read_f32_at knows: anything else is refused before any launch
+    assert lib.rmnet_bank_read_f32_at(None, 1, 1, 4, 4, 1, None, 8, None, None, None, None, None, 0, None, None, None, None) == -1
