@@ -307,6 +307,15 @@ def loop_fps(net, tfn, dev, B, K, n_obj, H, W, T_mem, steps, seed0=100):
             'mask_channels': K, 'frame': '%dx%d' % (H, W), 'memory_frames': T_mem, 'steps': steps}
 
 
+_T_START = time.perf_counter()
+
+
+def _phase(name):
+    """Wall-clock log of the run's phases on stderr (the JSON line on stdout stays alone)."""
+    if os.environ.get('RANK', '0') == '0':
+        print('[bench %7.1f s] %s' % (time.perf_counter() - _T_START, name), file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -350,6 +359,7 @@ def main():
     torch.set_grad_enabled(False)
     torch.backends.cudnn.benchmark = not args.no_miopen_find
 
+    _phase('imports done')
     net = networks.procedural_init_(RMNet(None, read_precision=args.read_precision)).to(dev).eval()
     tfn = networks.procedural_init_(TinyFlowNet(None)).to(dev).eval()
     if args.fold_bn:
@@ -418,6 +428,7 @@ def main():
             graph.replay()
             return s_out
 
+    _phase('memory filled (MIOpen find of the headline shapes done)')
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -431,6 +442,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = rd.max_over_ranks(time.perf_counter() - t0)
     assert bool(torch.isfinite(out).all())
+    _phase('timed region done')
     if args.graph:
         # events cannot be read back from inside a replayed graph: time the kernel on the same state
         # with an eager pass right after the timed region
@@ -491,6 +503,7 @@ def main():
     extras = None
     if rank == 0 and world == 1 and not args.no_extras:
         extras = {}
+        _phase('extras: single stream')
         # ---- one clip alone (single stream): same step, B = 1
         ctx1 = net._ClipContext(net, 1, K_CH, H, W, [K_CH - 1], dev)
         bank1 = net.new_bank(ctx1, T_MEM)
@@ -548,6 +561,7 @@ def main():
             extras['single_stream_graph_error'] = repr(exc)[:300]
         # ---- free-running loop: RMNet.forward on one 67-frame clip (DAVIS-val mean length), memorize_every = 5,
         #      estimated masks fed back (the real feedback edge), TinyFlowNet inside the timed region
+        _phase('extras: free-running clip')
         from rmnet_amd.synthetic import synthetic_clip as _clip
         N_FREE = 67
         ff, fm, _, fn_obj = _clip(N_FREE, K_CH, H, W, seed=7, size=2.1)
@@ -586,15 +600,25 @@ def main():
                                   'note': 'RMNet.forward + TinyFlowNet on one clip, masks fed back; with random-init weights the '
                                           'estimated object covers %.0f %% of the frame on average (boxes follow it)' % (100 * cover)}
         del ff, est, est_g, est_o
+        _phase('extras: loops at the other configurations')
         # ---- whole-loop frames/s at the other BASELINE configurations: same step as the headline, other shapes
+        # (MIOpen immediate mode here: a find pass for each of these shape sets costs ~90 s of wall time per configuration
+        #  and the default run has to stay within minutes; measured with find: 60.2 / 65.5 / 44.0 / 250.7 frames/s)
+        torch.backends.cudnn.benchmark = False
         extras['loops'] = {
             'cfg2_5obj_T5_480p_1clip': loop_fps(net, tfn, dev, 1, 6, 5, H, W, 5, 10),
             'cfg2_5obj_T5_480p_4clips': loop_fps(net, tfn, dev, 4, 6, 5, H, W, 5, 6),
             'cfg4_3obj_T20_720p_1clip': loop_fps(net, tfn, dev, 1, 4, 3, 720, 1280, 20, 6),
             'loader_K11_1obj_T5_480p_8clips': loop_fps(net, tfn, dev, 8, 11, 1, H, W, 5, 10),
             'note': 'memory pinned at T (T - 1 committed frames + the tentative previous frame); prev-frame masks = the synthetic '
-                    'blobs; K = 11 mirrors the reference test loader (config.py:137): 10 of the 11 channels are empty for a 1-object clip'}
+                    'blobs; K = 11 mirrors the reference test loader (config.py:137): 10 of the 11 channels are empty for a 1-object clip.  '
+                    'MIOpen immediate mode for these four (no find pass: it costs ~90 s of wall time per shape set); with find '
+                    'the same loops measured 60.2 / 65.5 / 44.0 / 250.7 frames/s (profiles/r03_a_bench_line.json history)',
+            'miopen_find': False}
+        torch.backends.cudnn.benchmark = not args.no_miopen_find
+        _phase('extras: kernels one by one')
         extras['kernels'] = kernel_figures(dev, events)
+        _phase('extras done')
 
     if rank == 0:
         line = {
@@ -658,6 +682,7 @@ def main():
             line['extras'] = extras
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
+            _phase('cpu baseline done')
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as tdist
