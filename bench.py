@@ -658,7 +658,9 @@ def main():
                                   'note': 'executed = the MFMA terms of the mode (split: hi*hi + hi*lo + lo*hi; f16: one) over the compacted 64-query x 32-cell tiles incl. '
                                           'padding; useful = one term over the un-padded regional cells; dense = SURVEY 8d '
                                           '2*THW*hw*(De+Do) per object-frame as if nothing were masked.  The kernel is power-capped on the '
-                                          'matrix pipe (profiles/r03_power_ceiling.md): a pure random-data MFMA loop sustains 1.7-1.9 PFLOP/s'},
+                                          'matrix pipe (profiles/r03_power_ceiling.md): a pure random-data MFMA loop sustains 1.7-1.9 PFLOP/s.  SQ counters of the same kernel '
+                                          '(profiles/r03_d_mfma_pmc.md): SQ_VALU_MFMA_BUSY_CYCLES = 87,336 cycles per SIMD per launch of the default mode = 47-50 % of '
+                                          'the un-profiled launch (68 % during the tile walks), 26-27 % for the fp16-operand mode'},
                          'launches': args.steps,
                          'avg_us': round(main_avg * 1e3, 2), 'avg_us_event_bracket': round(main_raw * 1e3, 2),
                          'event_floor_us': round(ev_floor_us, 2), 'min_us_event_bracket': round(min(main_ms) * 1e3, 2),
