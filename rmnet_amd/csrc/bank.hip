@@ -1164,7 +1164,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
   __shared__ int o_njt[kMaxObj], o_m[kMaxObj], o_nqt[kMaxObj], o_cb[kMaxObj], o_sb[kMaxObj];
   __shared__ int o_rect[kMaxObj][4];
-  __shared__ int plan_n, plan_c, sflag;
+  __shared__ int plan_n, plan_c, plan_own, sflag;
   char* Kl_ = lds;                                 // [ring slot][plane][8 KB]
   char* Pl_ = lds + 8 * kKbuf;                     // [buf][ntile][plane][lane*16]
   float* Al = reinterpret_cast<float*>(Pl_ + 3 * kPbuf);
@@ -1246,7 +1246,8 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     int C0 = max((W + target - 1) / target, bank_chunk_min(njt_max));
     C0 = (C0 + kCq - 1) / kCq * kCq;
     for (int it = 0; it < 1024 && wave_sum(bank_chunks(nqt, njt, C0, kSC).nch) > target; ++it) C0 += (1 + (C0 >> 5) + kCq - 1) / kCq * kCq;
-    const BankChunks bc0 = bank_chunks(nqt, njt, C0, kSC);
+    const bool own = wave_sum(bank_chunks(nqt, njt, C0, kSC, true).nch) <= target;   // short objects as blocks of their own (common.h)
+    const BankChunks bc0 = bank_chunks(nqt, njt, C0, kSC, own);
     int nch = bc0.nch, nsl = bc0.nch + (bc0.R > 0 ? nqt : 0);   // chunks; slots (a remainder chunk can add one per query tile)
     const int my_ch = nch, my_sl = nsl;
 #pragma unroll
@@ -1255,7 +1256,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
       if (tid >= d) { nch += u1; nsl += u2; }
     }
     if (tid < ng) { o_cb[tid] = nch - my_ch; o_sb[tid] = nsl - my_sl; }
-    if (tid == RMNET_WAVE - 1) { plan_n = nch; plan_c = bc0.C; }
+    if (tid == RMNET_WAVE - 1) { plan_n = nch; plan_c = bc0.C; plan_own = own ? 1 : 0; }
   }
   __syncthreads();
   auto sld = [](const int& x) { return __builtin_amdgcn_readfirstlane(x); };   // LDS value -> SGPR
@@ -1284,7 +1285,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   for (int i = 1; i < ng; ++i)
     if (sld(o_cb[i]) <= c) og = i;          // (objects without chunks share the next one's base: the later one wins)
   const int nqt = sld(o_nqt[og]), njt = sld(o_njt[og]);
-  const BankChunks bc = bank_chunks(nqt, njt, C, kTerms == 1 ? kSegCostF16 : kSegCost);
+  const BankChunks bc = bank_chunks(nqt, njt, C, kTerms == 1 ? kSegCostF16 : kSegCost, sld(plan_own) != 0);
   const int cl = c - sld(o_cb[og]);         // chunk inside the object
   const int lane = tid & 63;
   Walk wk;
@@ -1570,8 +1571,8 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   if (cl < nqt * bc.nfull) {          // aligned chunk: (column block, query tile), one segment
     const int blk = cl / nqt;
     wk.qt = cl - blk * nqt;
-    wk.jt0 = blk * C;
-    wk.ntl = C;
+    wk.jt0 = blk * bc.Cb;
+    wk.ntl = bc.Cb;
     wk.slot = slot_obj + cl;
     run_segment(blk);
     return;
@@ -1584,7 +1585,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     const int j0 = max(u0 - qt * span, 0), j1 = min(u1 - qt * span, bc.R);   // tiles of pair qt inside the chunk
     if (j1 <= j0) continue;
     wk.qt = qt;
-    wk.jt0 = bc.nfull * C + j0;
+    wk.jt0 = bc.nfull * bc.Cb + j0;
     wk.ntl = j1 - j0;
     wk.slot = slot_obj + nqt * bc.nfull + cr + qt;
     if (!first) __syncthreads();      // the previous segment's LDS (K ring, P, alpha, epilogue scratch) is free

@@ -171,13 +171,21 @@ constexpr int kSegCost = RMNET_SEG_COST;
 #define RMNET_SEG_COST_F16 12   // fp16-operand mode: a tile costs a third, a segment's fixed part does not
 #endif
 constexpr int kSegCostF16 = RMNET_SEG_COST_F16;
-struct BankChunks { int C, nfull, R, nrem, nch, sc; };
-__host__ __device__ inline BankChunks bank_chunks(int nqt, int njt, int C, int segcost = kSegCost) {
+struct BankChunks { int C, Cb, nfull, R, nrem, nch, sc; };
+__host__ __device__ inline BankChunks bank_chunks(int nqt, int njt, int C, int segcost = kSegCost, bool own_blocks = false) {
   BankChunks k;
   k.C = C;
   k.sc = segcost;
+  k.Cb = C;                          // length of an aligned column block
   k.nfull = njt / C;
   k.R = njt - k.nfull * C;
+  // An object with no more tiles than a chunk is ONE column block of its own length: nqt single-segment chunks that
+  // walk the same tiles in lockstep.  As a "remainder" its pairs would be cut at shifted positions, every workgroup
+  // would stream its own copy of the tiles, and two such objects per XCD do not fit the L2 (measured, 16 objects of
+  // 120 tiles at C = 122: 164 us against 118 us for 15 objects at C = 108).
+  // `own_blocks` is a launch-wide decision of the plan: C is found WITHOUT it (the chunk count then falls as C grows, so
+  // a launch with more pairs than workgroups still fits); it is switched on if the launch still fits with it.
+  if (own_blocks && njt > 0 && njt <= C) { k.Cb = njt; k.nfull = 1; k.R = 0; }
   k.nrem = k.R > 0 && nqt > 0 ? (nqt * (k.R + segcost) - segcost + C - 1) / C : 0;   // (no query tile: no chunk)
   k.nch = nqt * k.nfull + k.nrem;
   return k;
