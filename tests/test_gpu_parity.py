@@ -305,6 +305,8 @@ def _fill_bank(ops, mk, mv, mr, capacity=None):
     (70, 1, 4, 5, True),      # > 64 objects: two launch groups
     (5, 3, 30, 54, True),     # boxes of very different sizes planned together
     (5, 5, 30, 54, True),     # BASELINE configs[2] at its exact shape: 5 objects, T = 5, 480p grid
+    (50, 2, 12, 20, False),   # 200 equal pairs of 16 tiles on ~230 workgroups: every object a column block of its own (C > njt)
+    (24, 3, 12, 20, True),    # ragged version of the same regime
     (1, 3, 30, 54, True)])    # BASELINE configs[0]: 1 object, 3 memory frames
 def test_bank_read_vs_oracle(no, T, h, w, regional, oracle_mod):
     """The split-fp16 bank path (what the frame loop uses) against the oracle, same tolerance as the
@@ -1469,7 +1471,7 @@ def _f16_bars(got, want, vmax, smax=0.0):
 @pytest.mark.parametrize('no,T,h,w,regional', [
     (1, 1, 4, 5, False), (2, 3, 9, 13, True), (1, 5, 30, 54, True), (1, 7, 16, 24, False), (2, 9, 10, 7, True),
     (14, 2, 6, 9, True), (70, 1, 4, 5, True), (5, 3, 30, 54, True), (5, 5, 30, 54, True), (3, 20, 12, 20, True),
-    (1, 70, 5, 6, True)])
+    (1, 70, 5, 6, True), (50, 2, 12, 20, False), (24, 3, 12, 20, True)])
 def test_bank_read_f16_mode_vs_oracle(no, T, h, w, regional, oracle_mod):
     """Same cases as test_bank_read_vs_oracle (ragged boxes, empty boxes, > 12 and > 64 objects, odd tile counts --
     a step of the fp16 loop is TWO tiles, which may belong to different frames), fp16-operand arithmetic."""
