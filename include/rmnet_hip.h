@@ -110,7 +110,7 @@ int rmnet_boxes_to_cell_rects_i32(const int32_t *bboxes, int n_boxes, int k_per_
  * RMNET_MR_EXACT_FP32 forces the exact kernel.  Parity with the reference is a tolerance (see tests).
  * RMNET_MR_F16 (opt-in) reads the staged bank with its hi planes only: K, V, the query and the soft-max weights enter
  * the MFMAs rounded to fp16 (11 significant bits), fp32 accumulate -- one MFMA term instead of three and half the bank
- * bytes, about twice as fast.  Error of a read-out: about 2^-11 of the values it averages (3e-4 relative at worst, a
+ * bytes, 1.5-2x as fast.  Error of a read-out: about 2^-11 of the values it averages (3e-4 relative at worst, a
  * peaked soft-max returning one cell's value; 5e-6 absolute when hundreds of cells contribute), against 1e-7 for the
  * default.  It meets the bar the reference's task sets (mask IoU within 1e-3 on whole clips, tests/test_gpu_parity.py);
  * it is NOT fp32-class.  Same range rules and the same device-side fallback as the default.
@@ -171,7 +171,7 @@ int rmnet_memory_read_f32_ev(const float *m_key, const float *m_val, const float
  *       rmnet_bank_area_offset(): byte offset of the int32 [no][Tcap] table of cells stored per slot (accounting).
  *       Tcap <= 2048.
  * rmnet_bank_read_f32_at(..., flags): 0 = the arithmetic above; RMNET_BANK_F16 = hi planes only (see RMNET_MR_F16: fp16
- *       operands, fp32 accumulate, ~2^-11 relative, about twice as fast).  The bank is the same either way: a clip
+ *       operands, fp32 accumulate, ~2^-11 relative, 1.5-2x as fast).  The bank is the same either way: a clip
  *       can be memorised once and read in both modes.
  * ------------------------------------------------------------------------------------------- */
 size_t rmnet_bank_bytes(int no, int Tcap, int h, int w);

@@ -49,7 +49,7 @@ class MemoryReader(nn.Module):
     def __init__(self, return_affinity=False, precision='split'):
         super().__init__()
         self.return_affinity = return_affinity
-        self.precision = ops._precision(precision)     # 'f16': fp16 operands, about twice as fast, ~2^-11 relative (ops.MR_F16)
+        self.precision = ops._precision(precision)     # 'f16': fp16 operands, 1.5-2x as fast, ~2^-11 relative (ops.MR_F16)
 
     def forward(self, m_key, m_val, q_key, q_val, mem_rects=None, qry_rects=None, T=None):
         return ops.memory_read(m_key.contiguous(), m_val.contiguous(), q_key.contiguous(),
@@ -68,7 +68,7 @@ class RMNet(nn.Module):
         super().__init__()
         self.cfg = cfg
         # arithmetic of the bank read in the frame loop: 'split' = fp16 hi/lo pairs, fp32-class (default);
-        # 'f16' = fp16 operands with fp32 accumulate, about twice as fast, ~2^-11 relative per read-out -- inside the
+        # 'f16' = fp16 operands with fp32 accumulate, 1.5-2x as fast, ~2^-11 relative per read-out -- inside the
         # reference task's bar (mask IoU within 1e-3, tests/test_gpu_parity.py) but not fp32-class
         self.read_precision = ops._precision(read_precision)
         self.encoder_memory = EncoderMemory()
