@@ -1,0 +1,164 @@
+// Host-side check of the bank read's launch plan (rmnet_amd/csrc/common.h: bank_chunks; rmnet_amd/csrc/bank.hip: the
+// chunk -> segment walk of bk_main and pair_slots).  No GPU, no HIP API call: hipcc only supplies the __host__ __device__
+// qualifiers of common.h.  tests/test_host_logic.py builds and runs it.
+//
+// The chunk walk and pair_slots() are device code inside bank.hip's anonymous namespace and cannot be included, so they
+// are RESTATED here, statement by statement (bank.hip "aligned chunk" / "remainder chunk" and pair_slots); what is under
+// test is bank_chunks() itself -- the real function -- and the invariants the kernel relies on:
+//   1. every (query tile, memory tile) of an object is walked by exactly one segment;
+//   2. every segment's partial slot is unique and below the object's slot budget nch + (R > 0 ? nqt : 0);
+//   3. the segments of a pair sit at positions 0 .. count-1 of the pair's slot list, and that list (the closed form the
+//      last arriver merges from) names exactly their slots;
+//   4. a chunk never starts more segments than the merge scratch allows, no chunk is longer than C tile units;
+//   5. the plan's search for C ends with no more chunks than workgroups, with and without "own column blocks".
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <random>
+#include <set>
+#include <vector>
+
+#include "../../rmnet_amd/csrc/common.h"
+
+using namespace rmnet;
+
+namespace {
+
+struct Seg { int qt, j0, n, slot, sself; };
+
+// bank.hip, compute(): the segments of chunk `cl` of one object (slot_obj = 0)
+std::vector<Seg> chunk_segments(const BankChunks& bc, int nqt, int cl) {
+  std::vector<Seg> out;
+  const int C = bc.C;
+  if (cl < nqt * bc.nfull) {
+    const int blk = cl / nqt;
+    out.push_back({cl - blk * nqt, blk * bc.Cb, bc.Cb, cl, blk});
+    return out;
+  }
+  const int cr = cl - nqt * bc.nfull;
+  const int u0 = cr * C, u1 = u0 + C, span = bc.R + bc.sc;
+  for (int qt = u0 / span; qt < nqt && qt * span < u1; ++qt) {
+    const int j0 = std::max(u0 - qt * span, 0), j1 = std::min(u1 - qt * span, bc.R);
+    if (j1 <= j0) continue;
+    out.push_back({qt, bc.nfull * bc.Cb + j0, j1 - j0, nqt * bc.nfull + cr + qt, bc.nfull + cr - (qt * span) / C});
+  }
+  return out;
+}
+
+// bank.hip, pair_slots(): slot list of pair qt (sb = 0)
+std::vector<int> pair_slot_list(const BankChunks& bc, int nqt, int qt) {
+  std::vector<int> s;
+  for (int i = 0; i < bc.nfull; ++i) s.push_back(qt + i * nqt);
+  if (bc.R > 0) {
+    const int v0 = qt * (bc.R + bc.sc);
+    const int cf = v0 / bc.C, cl = (v0 + bc.R - 1) / bc.C;
+    for (int c = cf; c <= cl; ++c) s.push_back(nqt * bc.nfull + c + qt);
+  }
+  return s;
+}
+
+int fails = 0;
+#define CHECK(cond, ...)                                   \
+  do {                                                     \
+    if (!(cond)) {                                         \
+      if (fails < 20) { std::printf("FAIL %s: ", #cond); std::printf(__VA_ARGS__); std::printf("\n"); } \
+      ++fails;                                             \
+    }                                                      \
+  } while (0)
+
+void check_object(int nqt, int njt, int C, int sc, bool own) {
+  const BankChunks bc = bank_chunks(nqt, njt, C, sc, own);
+  if (nqt == 0 || njt == 0) {
+    CHECK(bc.nch == 0 || njt == 0 || nqt == 0, "nqt %d njt %d C %d", nqt, njt, C);
+    CHECK(bc.nch >= 0 && bc.nrem >= 0, "negative chunk count: nqt %d njt %d C %d sc %d -> nch %d nrem %d", nqt, njt, C, sc, bc.nch, bc.nrem);
+    if (nqt == 0) CHECK(bc.nch == 0, "an object without query tiles has chunks: njt %d C %d sc %d nch %d", njt, C, sc, bc.nch);
+    return;
+  }
+  CHECK(bc.nch == nqt * bc.nfull + bc.nrem, "nch");
+  CHECK(bc.nfull * bc.Cb + bc.R == njt, "tiles: nfull %d Cb %d R %d njt %d", bc.nfull, bc.Cb, bc.R, njt);
+  const int nsl = bc.nch + (bc.R > 0 ? nqt : 0);
+  std::vector<std::vector<int>> cover(nqt, std::vector<int>(njt, 0));
+  std::set<int> slots;
+  std::map<int, std::vector<Seg>> by_pair;
+  for (int cl = 0; cl < bc.nch; ++cl) {
+    const std::vector<Seg> segs = chunk_segments(bc, nqt, cl);
+    int units = 0;
+    for (const Seg& s : segs) {
+      CHECK(s.n > 0 && s.j0 >= 0 && s.j0 + s.n <= njt, "segment range qt %d j0 %d n %d (njt %d C %d)", s.qt, s.j0, s.n, njt, C);
+      for (int j = s.j0; j < s.j0 + s.n && j < njt; ++j) ++cover[s.qt][j];
+      CHECK(s.slot >= 0 && s.slot < nsl, "slot %d outside [0, %d): nqt %d njt %d C %d sc %d own %d", s.slot, nsl, nqt, njt, C, sc, (int)own);
+      CHECK(slots.insert(s.slot).second, "slot %d used twice: nqt %d njt %d C %d sc %d", s.slot, nqt, njt, C, sc);
+      by_pair[s.qt].push_back(s);
+      units += s.n;
+    }
+    CHECK(units <= C, "chunk %d walks %d tiles > C %d", cl, units, C);
+  }
+  for (int qt = 0; qt < nqt; ++qt)
+    for (int j = 0; j < njt; ++j)
+      CHECK(cover[qt][j] == 1, "pair %d tile %d covered %d times: nqt %d njt %d C %d sc %d own %d", qt, j, cover[qt][j], nqt, njt, C, sc, (int)own);
+  for (int qt = 0; qt < nqt; ++qt) {
+    const std::vector<int> list = pair_slot_list(bc, nqt, qt);
+    std::vector<Seg>& segs = by_pair[qt];
+    CHECK(segs.size() == list.size(), "pair %d: %zu segments, slot list of %zu: nqt %d njt %d C %d sc %d", qt, segs.size(), list.size(), nqt, njt, C, sc);
+    CHECK((int)list.size() <= kSplitMax, "pair %d has %zu partials > kSplitMax", qt, list.size());
+    std::set<int> pos;
+    for (const Seg& s : segs) {
+      CHECK(s.sself >= 0 && s.sself < (int)list.size(), "sself %d outside the pair's list of %zu", s.sself, list.size());
+      if (s.sself >= 0 && s.sself < (int)list.size())
+        CHECK(list[s.sself] == s.slot, "pair %d position %d: list says slot %d, the segment owns %d (nqt %d njt %d C %d sc %d own %d)", qt, s.sself,
+              list[s.sself], s.slot, nqt, njt, C, sc, (int)own);
+      CHECK(pos.insert(s.sself).second, "position %d of pair %d taken twice", s.sself, qt);
+    }
+  }
+}
+
+// bank.hip, the plan: smallest chunk length whose chunks fit `target` workgroups, then "own column blocks" if they fit too
+void check_launch(const std::vector<int>& nqt, const std::vector<int>& njt, int target, int sc, int cq) {
+  long long W = 0;
+  int njt_max = 0;
+  for (size_t o = 0; o < nqt.size(); ++o) { W += (long long)nqt[o] * njt[o]; njt_max = std::max(njt_max, njt[o]); }
+  auto total = [&](int C, bool own) { int n = 0; for (size_t o = 0; o < nqt.size(); ++o) n += bank_chunks(nqt[o], njt[o], C, sc, own).nch; return n; };
+  int C0 = std::max((int)((W + target - 1) / target), bank_chunk_min(njt_max));
+  C0 = (C0 + cq - 1) / cq * cq;
+  int it = 0;
+  for (; it < 1024 && total(C0, false) > target; ++it) C0 += (1 + (C0 >> 5) + cq - 1) / cq * cq;
+  CHECK(it < 1024, "the search for C did not end (W %lld target %d)", W, target);
+  CHECK(total(C0, false) <= target, "more chunks (%d) than workgroups (%d)", total(C0, false), target);
+  const bool own = total(C0, true) <= target;
+  for (size_t o = 0; o < nqt.size(); ++o) check_object(nqt[o], njt[o], C0, sc, own);
+}
+
+}  // namespace
+
+int main() {
+  // 1. bank_chunks on a dense sweep of single objects (both segment costs, with and without own blocks)
+  for (int sc : {kSegCost, kSegCostF16})
+    for (int nqt = 0; nqt <= 14; ++nqt)
+      for (int njt = 0; njt <= 150; njt += (njt < 40 ? 1 : 7))
+        for (int C = 4; C <= 160; C += (C < 30 ? 1 : 5))
+          for (int own = 0; own < 2; ++own) check_object(nqt, njt, C, sc, own != 0);
+  // 2. whole launches: the shapes of the tests / the bench, and random mixes (empty objects, many equal objects)
+  const int targets[] = {256, 232, 209, 192, 64};
+  std::mt19937 rng(7);
+  std::vector<std::pair<std::vector<int>, std::vector<int>>> launches = {
+      {std::vector<int>(8, 12), std::vector<int>(8, 120)},  {std::vector<int>(16, 12), std::vector<int>(16, 120)},
+      {std::vector<int>(20, 12), std::vector<int>(20, 120)}, {std::vector<int>(32, 12), std::vector<int>(32, 120)},
+      {std::vector<int>(50, 4), std::vector<int>(50, 16)},   {std::vector<int>(64, 1), std::vector<int>(64, 1)},
+      {{14, 13, 12, 11, 9}, {140, 120, 100, 90, 75}},        {{57, 57, 57}, {1040, 1040, 1040}}, {{26}, {120}}};
+  for (int r = 0; r < 400; ++r) {
+    const int ng = 1 + rng() % 64;
+    std::vector<int> q(ng), j(ng);
+    const int qmax = 1 + rng() % 57, jmax = 1 + rng() % (r % 3 ? 200 : 1100);
+    for (int o = 0; o < ng; ++o) { q[o] = rng() % 9 == 0 ? 0 : 1 + rng() % qmax; j[o] = rng() % 11 == 0 ? 0 : 1 + rng() % jmax; }
+    launches.push_back({q, j});
+  }
+  for (const auto& l : launches)
+    for (int t : targets) {
+      check_launch(l.first, l.second, t, kSegCost, 1);
+      check_launch(l.first, l.second, t, kSegCostF16, 2);
+    }
+  if (fails) { std::printf("plan_check: %d failures\n", fails); return 1; }
+  std::printf("plan_check ok: %zu launches x %zu targets x 2 modes\n", launches.size(), sizeof(targets) / sizeof(targets[0]));
+  return 0;
+}

@@ -339,3 +339,23 @@ def test_fused_epilogue_snapshots_follow_submodule_checkpoint_loads():
     assert torch.allclose(stem._s1, networks._bn_scale_shift(stem.bn1)[0])
     net.fuse_epilogues(False)
     assert all(getattr(m, '_fuse_hook', None) is None for m in net.modules())
+
+
+def test_launch_plan_invariants_on_the_host(tmp_path):
+    """tests/native/plan_check.cpp: the real bank_chunks() of csrc/common.h under the chunk walk and the pair slot lists of
+    bk_main (restated there), over a dense sweep of single objects and ~400 whole launches x 5 workgroup budgets x both
+    arithmetic modes: every (query tile, memory tile) walked once, slots unique and inside the budget, a pair's segments at
+    the positions its closed-form slot list names, the search for the chunk length ending inside the workgroup budget.
+    (Both plan bugs of round 3 -- a negative chunk count for objects without query tiles, own-column-block plans that did
+    not fit the launch -- are of the kind this catches without a GPU.)"""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    exe = str(tmp_path / 'plan_check')
+    cc = subprocess.run([hipcc, '-O1', '-std=c++17', '-w', '--offload-arch=gfx950', os.path.join(ROOT, 'tests', 'native', 'plan_check.cpp'), '-o', exe],
+                        capture_output=True, text=True, timeout=600)
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and 'plan_check ok' in run.stdout, run.stdout[-3000:]
