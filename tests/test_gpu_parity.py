@@ -1379,6 +1379,29 @@ def test_memory_longer_than_512_frames(oracle_mod):
         np.testing.assert_allclose(got.cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL)
 
 
+def test_bank_at_its_slot_limit(oracle_mod):
+    """The bank's documented limit: 2048 memorised frames are read (both arithmetic modes, a 3x4 grid keeps the oracle fast:
+    the workgroups' LDS tile prefix is full), a bank of 2049 slots is refused with RMNET_E_UNSUPPORTED, not clamped."""
+    from rmnet_amd import _lib, ops
+    assert ops.BANK_MAX_SLOTS == 2048
+    rng = np.random.RandomState(2048)
+    no, T, h, w = 1, 2048, 3, 4
+    mk, mv, qk, qv, mr, qr = _random_case(rng, no, T, h, w, regional=True)
+    want, _ = oracle_mod.regional_memory_read(mk, mv, qk, qv, mr, qr)
+    bank = ops.MemoryBank(no, T, h, w, dev())
+    lib = _lib.load()
+    for t in range(T):
+        bank.append(t, cu(mk[:, :, t]), cu(mv[:, :, t]), cu(mr[:, t]))
+    np.testing.assert_allclose(bank.read(T, cu(qk), cu(qv), cu(qr)).cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL)
+    bank.precision = 'f16'
+    _f16_bars(bank.read(T, cu(qk), cu(qv), cu(qr)).cpu().numpy(), want, float(np.abs(mv).max()))
+    assert bank.overflow_count() == 0
+    big = torch.zeros(lib.rmnet_bank_bytes(1, 2049, h, w) or 1 << 20, dtype=torch.uint8, device=dev())
+    k4, v4 = cu(mk[:, :, 0]), cu(mv[:, :, 0])
+    rc = lib.rmnet_bank_append_f32(big.data_ptr(), 1, 2049, h, w, 0, k4.data_ptr(), v4.data_ptr(), None, None)
+    assert rc == -4, rc                                            # RMNET_E_UNSUPPORTED
+
+
 def test_forward_replays_one_hip_graph_for_the_whole_clip(oracle_mod):
     """RMNet.forward captures the frame step once (second segmented frame) and replays it while the memory
     grows -- the bank's slot / frame count are a DEVICE counter, not kernel arguments.  A 10-frame clip with memorize_every = 3
