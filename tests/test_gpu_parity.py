@@ -1621,3 +1621,33 @@ def test_f16_mode_multi_object_clips_against_the_default_mode(oracle_mod):
             b = prod(frames, masks, flows, n_objects, every).argmax(2).cpu().numpy()
         for k in range(1, n_obj + 1):
             assert oracle_mod.iou(a[:, 1:] == k, b[:, 1:] == k) >= bar, (n_obj, k)
+
+
+def test_f16_mode_through_strides_partial_reads_and_graph_replay(oracle_mod):
+    """The fp16-operand switch on the remaining call shapes: the drop-in entry with a memory tensor of capacity > T (channel
+    strides, a late spike that bumps the deferred maximum in the middle of a two-tile step); and the frame loop with
+    ``read_precision='f16'`` replayed as one HIP graph == the same loop run eagerly (the flag is baked into the capture)."""
+    from rmnet_amd import networks, ops
+    from rmnet_amd.rmnet import RMNet
+    from rmnet_amd.synthetic import synthetic_clip
+    rng = np.random.RandomState(5)
+    no, T, Tcap, h, w = 2, 3, 5, 6, 10
+    mk, mv, qk, qv, mr, qr = _random_case(rng, no, Tcap, h, w, regional=True)
+    mk[:, :, 2, h - 1, w - 1] = qk[:, :, 2, 3] * 9.0
+    mr[:, 2] = (0, w - 1, 0, h - 1)
+    qr[:] = (0, w - 1, 0, h - 1)
+    want, _ = oracle_mod.regional_memory_read(mk[:, :, :T], mv[:, :, :T], qk, qv, mr[:, :T], qr)
+    got, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), cu(mr[:, :T]), cu(qr), T=T, flags=ops.MR_F16)
+    _f16_bars(got.cpu().numpy(), want, float(np.abs(mv).max()), smax=36.0)
+    want_d, _ = oracle_mod.memory_read(mk[:, :, :T], mv[:, :, :T], qk, qv)
+    got_d, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), T=T, flags=ops.MR_F16)
+    _f16_bars(got_d.cpu().numpy(), want_d, float(np.abs(mv).max()), smax=36.0)
+
+    net = networks.procedural_init_(RMNet(None, read_precision='f16')).to(dev()).eval()
+    net.fuse_epilogues()
+    frames, masks, flows, n_objects = synthetic_clip(9, 3, 96, 160, seed=17)
+    with torch.no_grad():
+        est_g = net(frames, masks, flows, n_objects, 3, graph=True).cpu()
+        est_e = net(frames, masks, flows, n_objects, 3, graph=False).cpu()
+    assert float((est_g - est_e).abs().max()) < 1e-3            # (MIOpen may pick another algorithm under capture)
+    assert (est_g.argmax(2) == est_e.argmax(2)).float().mean() > 0.999
