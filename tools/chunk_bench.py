@@ -36,8 +36,22 @@ floor = ev.floor_us(torch.cuda.current_stream(dev).cuda_stream)
 for _ in range(5):
     bank.read(T, qk, qv, qr)
 torch.cuda.synchronize()
+flush = int(os.environ.get('FLUSH', '0'))   # MB streamed between two reads (evicts L2 / MALL: the frame loop's condition)
+staged = os.environ.get('STAGED', '0') == '1' # frame count from the device counter (read_staged), as the frame loop reads
+if staged:
+    bank.committed = T - 1
+    bank.n_dev.fill_(T - 1)
+if flush:
+    fa = torch.empty(flush * 262144, device=dev)
+    fb = torch.ones(flush * 262144, device=dev)
 for i in range(reps):
-    bank.read(T, qk, qv, qr, events=tuple(ev.ev[3 * i:3 * i + 3]))
+    if flush:
+        fa.copy_(fb)
+        fa.mul_(1.0001)
+    if staged:
+        bank.read_staged(qk, qv, qr, events=tuple(ev.ev[3 * i:3 * i + 3]))
+    else:
+        bank.read(T, qk, qv, qr, events=tuple(ev.ev[3 * i:3 * i + 3]))
 torch.cuda.synchronize()
 bm = [ev.elapsed_ms(ev.ev[3 * i], ev.ev[3 * i + 1]) * 1e3 - floor for i in range(reps)]
 bc = [ev.elapsed_ms(ev.ev[3 * i + 1], ev.ev[3 * i + 2]) * 1e3 - floor for i in range(reps)]
