@@ -166,8 +166,13 @@ int rmnet_memory_read_f32_ev(const float *m_key, const float *m_val, const float
  *       16-byte group written with such an element increments the int32 overflow word that lives at byte
  *       rmnet_bank_overflow_offset() of the bank; a caller that cannot rule such inputs out checks it (once per
  *       clip is enough) and re-runs with rmnet_memory_read_f32(..., RMNET_MR_EXACT_FP32).
- *       The QUERY is split the same way after scaling by log2(e)/sqrt(128) * 2^6 (about 8.2): |q_key| beyond ~8e3 (or
- *       NaN / Inf in q_key) saturates WITHOUT being counted -- the overflow word covers what is memorised only.
+ *       The QUERY is split the same way after scaling by log2(e)/sqrt(128) * 2^6 (about 8.2): a q_key element inside the query box
+ *       with |x| beyond ~8e3 (or NaN / Inf) is counted in the same overflow word by the read itself (ABI v4; it used to saturate
+ *       silently), so "overflow word == 0 after the read" covers both sides.  The word also carries two sticky error bits:
+ *       1 << 30 = an append / read through a device counter hit a slot or frame count outside [0, Tcap] (nothing was written /
+ *       the count was clamped), 1 << 29 = a merge inside a read gave up waiting for another workgroup's partial (cannot happen on
+ *       a healthy device; the int32 right behind the overflow word counts these time-outs separately).  Any non-zero value means:
+ *       do not trust the reads of this bank, re-run exactly.
  *       rmnet_bank_area_offset(): byte offset of the int32 [no][Tcap] table of cells stored per slot (accounting).
  *       Tcap <= 2048.
  * rmnet_bank_read_f32_at(..., flags): 0 = the arithmetic above; RMNET_BANK_F16 = hi planes only (see RMNET_MR_F16: fp16

@@ -79,6 +79,9 @@ __device__ inline void split_f16(float x, _Float16& hi, _Float16& lo) {
 // back into the query scale (keys) and into the combine's normalisation (values).  An element beyond
 // +-1023.5 saturates and is COUNTED in the bank's overflow word (rmnet_bank_overflow_count).
 constexpr float kBankScale = 64.0f;      // 2^6
+// Sticky error bits of the overflow word (any non-zero value = "do not trust this bank's reads"):
+constexpr int kBankBadSlot = 1 << 30;    // an append / read with a slot or frame count outside [0, Tcap] (device counter out of step)
+constexpr int kBankTimeout = 1 << 29;    // a merge gave up waiting for a partial (also counted in the time-out word, ovf[1])
 __device__ inline bool split_scaled(float x, _Float16& hi, _Float16& lo) {
   const float y = x * kBankScale;
   split_f16(y, hi, lo);
@@ -166,7 +169,10 @@ __global__ __launch_bounds__(kThreads) void bk_append(BankView b, int slot0, con
   // slot_dev (optional): a device-resident frame counter added to slot0 -- lets a captured HIP graph of the frame
   // loop be replayed while the memory grows (the host never has to bake the slot into a kernel argument)
   if (slot_dev) slot0 += __builtin_amdgcn_readfirstlane(*slot_dev);
-  if (slot0 < 0 || slot0 + nf > b.Tcap) return;      // (a full bank: the host-side bookkeeping raises before this can happen)
+  if (slot0 < 0 || slot0 + nf > b.Tcap) {            // a full bank / a desynchronised device counter: nothing is written, and the
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) atomicOr(b.ovf, kBankBadSlot);   // bank says so
+    return;                                          // (rmnet_bank_overflow_count() != 0: the caller must not trust its reads)
+  }
   const int o = (int)blockIdx.y / nf, f = (int)blockIdx.y - o * nf, slot = slot0 + f;
   Rect rc{0, b.w - 1, 0, b.h - 1};
   if (rects) {
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(kThreads) void bk_append(BankView b, int slot0, con
 // grid = no * nf blocks of kDo threads: slot (o, slot0 + f)'s column sums = its tiles' sums in tile order.
 __global__ __launch_bounds__(kDo) void bk_colsum(BankView b, int slot0, const int32_t* __restrict__ slot_dev, int nf) {
   if (slot_dev) slot0 += __builtin_amdgcn_readfirstlane(*slot_dev);
-  if (slot0 < 0 || slot0 + nf > b.Tcap) return;
+  if (slot0 < 0 || slot0 + nf > b.Tcap) return;      // (bk_append has flagged it)
   const int o = (int)blockIdx.x / nf, f = (int)blockIdx.x - o * nf, d = threadIdx.x;
   const size_t so = (size_t)o * b.Tcap + slot0 + f;
   const int ntiles = (b.area[so] + kJT - 1) / kJT;
@@ -306,7 +312,9 @@ constexpr int kLdsBytes = 8 * kKbuf                        // K hi/lo x 4 ring s
                           + 3 * kPbuf                      // P buffers (two in the split mode, three in the fp16 mode)
                           + 3 * kQT * 4                    // alpha [buf][16 queries][4 query tiles]
                           + (kMaxT + 4) * 4                // tile prefix
-                          + kMaxT * 4;                     // cells per frame
+                          + kMaxT * 4                      // cells per frame
+                          + 4 * 256;                       // landing patches of the producers' L2 prefetch (fp16 mode)
+static_assert(kLdsBytes + 4096 <= kLdsBytesPerCU, "bk_main's LDS (tile rings + the prefix arrays of kMaxT frames + plan scratch) must fit one CU");
 constexpr int kProducers = 4;                              // waves 0-3
 constexpr int kConsumers = 8;                              // waves 4-11
 constexpr int kCDT = kDo / 16 / kConsumers;                // d-tiles (16 value channels) per consumer: 4
@@ -342,6 +350,21 @@ constexpr int kRThreads = 64 * (kProducers + kConsumers);  // 768 = 12 waves = 3
 #ifndef BK_F16_INTERLEAVE
 #define BK_F16_INTERLEAVE 6   // fp16 mode, producers: soft-max VALU instructions scheduled between two S MFMAs (0 = as the compiler likes)
 #endif
+#ifndef BK_PF
+#define BK_PF 7        // fp16 mode: L2 prefetch distance in steps (0 = off), see producer_loop_f16
+#endif
+#ifndef BK_PF_NLD
+#define BK_PF_NLD 1    // fp16 mode: prefetch loads per producer wave and step (256 lines each)
+#endif
+#ifndef BK_PF_DMA
+#define BK_PF_DMA 1    // fp16 mode: prefetch by LDS-DMA into a junk patch (no destination register, never waited for) instead of counted loads
+#endif
+#ifndef BK_PF_REM
+#define BK_PF_REM 0    // fp16 mode: remainder chunks prefetch all of their lines themselves (0 = they do not prefetch)
+#endif
+#ifndef BK_OUT_AUX
+#define BK_OUT_AUX 0   // cache policy of the stores to `out` (buffer aux bits: 2 = nt, 16 = sc1 write-through)
+#endif
 #ifndef BK_CLK
 #define BK_CLK 0       // experiments only: per-workgroup shader-cycle / real-time stamps behind the plan records
 #endif
@@ -366,6 +389,7 @@ struct Walk {          // per-workgroup constants of the tile walk (all wave-uni
   int slot;            // partial slot (absolute index)
   Rect qr;
   int t;               // frame of the first tile
+  int pf_part, pf_nparts;   // fp16 mode: this workgroup's share of the L2 prefetch (0 parts: none)
 };
 
 // Wave-uniform cursor over the split's tile list.  seek(j) clamps j to the split's last tile, which
@@ -436,6 +460,7 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
     // MFMAs in the log2 domain (times 2^12, see kSraw) and the soft-max is one fma + v_exp_f32 (= 2^x)
     // per element.
     const float keep = qvalid ? a.qscale : 0.0f;
+    bool qover = false;                 // a query element outside fp16's window after scaling (|q_key| > ~8e3), NaN or Inf
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -443,8 +468,10 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
         const float x = qb[(size_t)(32 * ks + 8 * g + e) * b.hw] * keep;
         _Float16 hi, lo;
         split_f16(x, hi, lo);
+        qover |= !(fabsf(x) <= 65504.0f);
         qh[ks][e] = hi; ql[ks][e] = lo;
       }
+    if (qover && qvalid) atomicAdd(b.ovf, 1);   // counted like a memorised element: the caller re-reads exactly (rmnet_hip.h)
   }
   float mref = -INFINITY, lsum = 0.0f;
 
@@ -797,15 +824,90 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
     }
     const float* qb = a.qk + (size_t)o * kDe * b.hw + cell;
     const float keep = qvalid ? a.qscale : 0.0f;
+    bool qover = false;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) qh[ks][e] = (_Float16)(qb[(size_t)(32 * ks + 8 * g + e) * b.hw] * keep);
+      for (int e = 0; e < 8; ++e) {
+        const float x = qb[(size_t)(32 * ks + 8 * g + e) * b.hw] * keep;
+        qover |= !(fabsf(x) <= 65504.0f);
+        qh[ks][e] = (_Float16)fminf(fmaxf(x, -65504.0f), 65504.0f);
+      }
+    if (qover && qvalid) atomicAdd(b.ovf, 1);   // (as in the split mode)
   }
   float mref = -INFINITY, lsum = 0.0f;
   half8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (_Float16)1.0f;
+
+  // ---- L2 prefetch.  Inside the frame loop nothing of the bank is in a cache when the read starts (the convolutions
+  // between two reads stream hundreds of MB), a V fragment load is issued ONE step (~1.3 us) before its use and an HBM
+  // miss under load takes longer than that: the tile walk then runs at memory latency, not at the matrix pipe's pace
+  // (measured in the loop: 1.77 us per step against 1.30 with a warm cache).  The nqt workgroups of a column block walk
+  // the same K / V tiles in lockstep on one XCD, i.e. behind one L2: each of them touches 1/nqt of the 128-byte lines of
+  // the step BK_PF steps ahead (one dword per line) so that the demand loads of all of them hit the L2.  Every producer
+  // wave issues exactly kPfLoads loads per step (lanes beyond the share repeat the share's first line: one request), so
+  // hipcc can count them; a value is "used" (an empty asm) two steps later, i.e. the wave never waits for a load that is
+  // less than two steps old.
+  constexpr int kPfLoads = BK_PF_NLD;
+  struct PfRegs { unsigned v[kPfLoads > 0 ? kPfLoads : 1]; };
+  Cursor cp;
+  cp.init(tpre, wk.t, jt0 + ntl - 1);
+  const size_t so0p = (size_t)o * b.Tcap;
+  const size_t tiles_per_slot_p = (size_t)(b.hwp / kJT);
+  constexpr int kPfLinesK = kJT * kDe * 2 / 128, kPfLinesV = kDo * kJT * 2 / 128, kPfLinesT = kPfLinesK + kPfLinesV;   // 64 + 256 per tile
+  const int pf_np = wk.pf_nparts > 0 ? wk.pf_nparts : 1 << 20;           // (no share: every lane repeats line 0)
+  auto prefetch_step = [&](int step, PfRegs& r_) {
+    const int ja = jt0 + 2 * step;
+    const int la = cp.seek(ja);                                          // (clamped to the segment's last tile)
+    const char* ka = b.kh + ((so0p + cp.tt) * b.hwp + (size_t)la * kJT) * kDe * sizeof(_Float16);
+    const char* va = b.vh + ((so0p + cp.tt) * tiles_per_slot_p + la) * (size_t)(kDo * kJT * 2);
+    const int lb = cp.seek(ja + 1);
+    const char* kb2 = b.kh + ((so0p + cp.tt) * b.hwp + (size_t)lb * kJT) * kDe * sizeof(_Float16);
+    const char* vb2 = b.vh + ((so0p + cp.tt) * tiles_per_slot_p + lb) * (size_t)(kDo * kJT * 2);
+#pragma unroll
+    for (int k = 0; k < kPfLoads; ++k) {
+      int i = ((k * kProducers + wave) * 64 + lane) * pf_np + wk.pf_part;
+      i = i < 2 * kPfLinesT ? i : (wk.pf_part < 2 * kPfLinesT ? wk.pf_part : 0);
+      const bool second = i >= kPfLinesT;
+      const int r = second ? i - kPfLinesT : i;
+      const bool isk = r < kPfLinesK;
+      const char* base = second ? (isk ? kb2 : vb2) : (isk ? ka : va);
+      r_.v[k] = *reinterpret_cast<const unsigned*>(base + (size_t)(isk ? r : r - kPfLinesK) * 128);
+    }
+  };
+  // LDS-DMA form: the touched dword lands in a 256-byte junk patch of this wave; no register, nothing ever waits for it
+  // (hipcc does not see the load: its own counted waits only get more conservative; __syncthreads() stays a bare barrier).
+  const unsigned pf_patch = __builtin_amdgcn_readfirstlane(
+      (unsigned)(size_t)(__attribute__((address_space(3))) char*)(Kl_ + kLdsBytes - 4 * 256 + wave * 256));
+  auto prefetch_dma = [&](int step) {
+    if (wk.pf_nparts <= 0) return;
+    const int ja = jt0 + 2 * step;
+    if (ja >= jt0 + ntl) return;                                         // (wave-uniform)
+    const int la = cp.seek(ja);
+    const char* ka = b.kh + ((so0p + cp.tt) * b.hwp + (size_t)la * kJT) * kDe * sizeof(_Float16);
+    const char* va = b.vh + ((so0p + cp.tt) * tiles_per_slot_p + la) * (size_t)(kDo * kJT * 2);
+    const int lb = cp.seek(ja + 1);                                      // (clamped to the segment's last tile)
+    const char* kb2 = b.kh + ((so0p + cp.tt) * b.hwp + (size_t)lb * kJT) * kDe * sizeof(_Float16);
+    const char* vb2 = b.vh + ((so0p + cp.tt) * tiles_per_slot_p + lb) * (size_t)(kDo * kJT * 2);
+    const int nl = (2 * kPfLinesT + wk.pf_nparts - 1) / wk.pf_nparts;    // lines of this workgroup
+    for (int l0 = wave * 64; l0 < nl; l0 += kProducers * 64) {           // (wave-uniform trip count)
+      int i = (l0 + lane) * wk.pf_nparts + wk.pf_part;
+      i = i < 2 * kPfLinesT ? i : wk.pf_part;                            // (past the share: a duplicate of its first line)
+      const bool second = i >= kPfLinesT;
+      const int r = second ? i - kPfLinesT : i;
+      const bool isk = r < kPfLinesK;
+      const char* base = second ? (isk ? kb2 : vb2) : (isk ? ka : va);
+      const char* ad = base + (size_t)(isk ? r : r - kPfLinesK) * 128;
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(ad), "s"(pf_patch) : "memory");
+    }
+  };
+  auto pf_use = [&](const PfRegs& r_) {
+#pragma unroll
+    for (int k = 0; k < kPfLoads; ++k) asm volatile("" :: "v"(r_.v[k]));
+  };
 
   struct Frags { half8 a0[4], a1[4], b0[4], b1[4]; };   // tile A cells 0-15 / 16-31, tile B cells 0-15 / 16-31
   auto k_frags = [&](Frags& f, int kslot) {             // 16 conflict-free ds_read_b128 (XOR-swizzled rows)
@@ -890,6 +992,15 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
   S4 sp;                           // S of the step whose soft-max comes next
   Frags f;
   int nva, nvb;                    // cell counts of that step
+  PfRegs pf_pro[BK_PF > 1 ? BK_PF - 1 : 1], pf_a, pf_b;
+  if (BK_PF && BK_PF_DMA) {
+#pragma unroll 1
+    for (int s_ = 1; s_ < BK_PF; ++s_) prefetch_dma(s_);
+  } else if (BK_PF) {
+#pragma unroll
+    for (int s_ = 1; s_ < BK_PF; ++s_) prefetch_step(s_, pf_pro[s_ - 1]);   // (step 0 and the K tiles of steps 1..4 are demand loads of the prologue)
+    pf_a = pf_pro[0]; pf_b = pf_pro[0];
+  }
   __syncthreads();                                   // A: K steps 0..3 in the ring
   {
     S4 s0, s1;
@@ -907,6 +1018,10 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
     soft_max(s1, 1);
     k_frags(f, 3);
     step_valid(2, nva, nvb);
+  }
+  if (BK_PF && !BK_PF_DMA) {
+#pragma unroll
+    for (int s_ = 1; s_ < BK_PF; ++s_) pf_use(pf_pro[s_ - 1]);
   }
   __syncthreads();                                   // B: P(0), P(1) visible; ring slot 0 free
   __syncthreads();                                   // C: K step 4 in slot 0
@@ -941,12 +1056,21 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
 #endif
     step_valid(n + 3, nva, nvb);                     // (LDS round trips: they end under the barrier)
     pbuf = pbuf == 2 ? 0 : pbuf + 1;
+    if (BK_PF && BK_PF_DMA) {
+      prefetch_dma(n + BK_PF);
+    } else if (BK_PF) {
+      pf_use(pf_a);
+      pf_a = pf_b;
+      prefetch_step(n + BK_PF, pf_b);
+    }
     BK_STAMP();   // K frags requested
     __syncthreads();
     BK_STAMP();   // after barrier
   }
   m_out = mref * kSraw;
   l_out = lsum;
+  if (BK_PF && BK_PF_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the patch is free again; the youngest touch is BK_PF steps old)
+  else if (BK_PF) { pf_use(pf_a); pf_use(pf_b); }
   BK_STAMP();
 }
 
@@ -1046,6 +1170,7 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
     nva = b.vh + v_tile(cv.tt, la);
     const int lb = cv.seek(jt0 + 2 * step + 1);
     nvb = b.vh + v_tile(cv.tt, lb);
+    if (BK_ABLATE & 4096) { nva = b.vh + v_tile(wk.t, 0); nvb = nva; }   // (experiment, wrong results: V fragments always from one hot tile)
   };
   v_next(1);
   for (int n = 0; n < nst; ++n) {
@@ -1186,7 +1311,9 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
 #endif
   const int ng = a.nobj;
   const int hw = b.hw;
-  const int T_ = min(max(a.T + (a.T_dev ? __builtin_amdgcn_readfirstlane(*a.T_dev) : 0), 1), b.Tcap);   // memorised frames to read
+  const int T_raw = a.T + (a.T_dev ? __builtin_amdgcn_readfirstlane(*a.T_dev) : 0);
+  const int T_ = min(max(T_raw, 1), b.Tcap);         // memorised frames to read (the clamp is memory safety only:
+  if (T_raw != T_ && blockIdx.x == 0 && tid == 0) atomicOr(b.ovf, kBankBadSlot);   // an out-of-range count is flagged)
   int* q_head = b.ovf + 16;                        // control block of the bank: static work queue (next item) ...
   int* q_exit = b.ovf + 32;                        // ... workgroups that have left the kernel (the last one zeroes both)
 
@@ -1418,12 +1545,18 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
       //      ticket, i.e. they have left their tile loops and only store -- the wait ends whatever else is (not) resident.
       if (tid == 0) {
         int polls = 0;
+        bool gave_up = false;
         while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nsp - 1) {
           __builtin_amdgcn_s_sleep(4);
-          if (++polls > (1 << 22)) { atomicAdd(b.ovf, 1 << 20); break; }   // (cannot happen; never hang the GPU: report as overflow)
+          if (++polls > (1 << 22)) { gave_up = true; break; }
         }
-        __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean counters for the next read
-        __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gave_up) {   // (cannot happen: the others hold a ticket and only store.  Never hang the GPU: count it in the time-out
+          atomicAdd(b.ovf + 1, 1);                                          // word, make the bank say "do not trust me" and leave
+          atomicOr(b.ovf, kBankTimeout);                                    // the counters alone -- late arrivers may still bump them;
+        } else {                                                            // the launcher clears the control block before every read)
+          __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean counters for the next read
+          __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
       if (BK_ABLATE & 1024) return;
       __syncthreads();                                                              // E2: all partials of the pair are in memory
@@ -1551,6 +1684,14 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
         cell = (wk.qr.cy0 + ry) * b.w + wk.qr.cx0 + (nq - ry * rw);
       }
       float* __restrict__ outo = a.out + (size_t)wk.o * 2 * kDo * hw + cell;
+#if BK_OUT_AUX
+      const __amdgpu_buffer_rsrc_t rs_out = [&]() {       // the read-out half of this object's output (wave-uniform base)
+        float* base = a.out + (size_t)wk.o * 2 * kDo * hw;
+        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(base));
+        const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(base) >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((uintptr_t)bhi << 32) | blo), 0, kDo * hw * 4, 0x00020000);
+      }();
+#endif
 #pragma unroll
       for (int dt = 0; dt < kCDT; ++dt) {
 #pragma unroll
@@ -1561,7 +1702,11 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
 #pragma unroll
         for (int ch = 0; ch < 16; ++ch) {
           const float x = T[ch * 65 + ln];
+#if BK_OUT_AUX
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rs_out, qvalid ? ((16 * (dt0 + dt) + ch) * hw + cell) * 4 : 0x40000000, 0, BK_OUT_AUX);
+#else
           if (qvalid) outo[(size_t)(16 * (dt0 + dt) + ch) * hw] = x;
+#endif
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -1574,6 +1719,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     wk.jt0 = blk * bc.Cb;
     wk.ntl = bc.Cb;
     wk.slot = slot_obj + cl;
+    wk.pf_part = wk.qt; wk.pf_nparts = nqt;
     run_segment(blk);
     return;
   }
@@ -1588,6 +1734,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     wk.jt0 = bc.nfull * bc.Cb + j0;
     wk.ntl = j1 - j0;
     wk.slot = slot_obj + nqt * bc.nfull + cr + qt;
+    wk.pf_part = 0; wk.pf_nparts = BK_PF_REM ? 1 : 0;
     if (!first) __syncthreads();      // the previous segment's LDS (K ring, P, alpha, epilogue scratch) is free
     first = false;
     run_segment(bc.nfull + cr - (qt * span) / C);
@@ -1735,8 +1882,8 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
               const int moff = (ul < pn && (m >> 4) == (V4 ? 15u : 1u)) ? off : kOOB;   // (mixed units: the list pass)
 #if !(BK_STATIC_ABL & 1)
               if (V4) {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rs_q, qoff, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(mu4, rs_m, moff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rs_q, qoff, 0, BK_OUT_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(mu4, rs_m, moff, 0, BK_OUT_AUX);
               } else {
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[0]), rs_q, qoff, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mu), rs_m, moff, 0, 0);

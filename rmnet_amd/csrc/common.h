@@ -7,6 +7,13 @@
 
 #define RMNET_WAVE 64
 
+// gfx950 only: the read kernels size their static LDS (one workgroup per CU) against CDNA4's 160 KB; on the 64 KB parts
+// (gfx90a / gfx942) they cannot be launched at all.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "librmnet_hip is written for gfx950 (MI355X): build with --offload-arch=gfx950"
+#endif
+constexpr int kLdsBytesPerCU = 160 * 1024;
+
 namespace rmnet {
 
 // Cell rectangle (cx0, cx1, cy0, cy1), inclusive; empty = (1, 0, 1, 0).
@@ -114,8 +121,10 @@ struct BankView {
   float* vpart;    // [no][Tcap][hwp/32][512] fp32: per 32-cell tile, the sum of the (un-scaled) values of its cells
   float* colsum;   // [no][Tcap][512] fp32: sum of a slot's values over the cells inside its box (bk_colsum)
   int32_t* area;   // [no][Tcap] cells inside the box of each memorised frame
-  int32_t* ovf;    // control block (256 B): [0] number of 16-byte groups written so far that held an element outside fp16's
-                   // window; [16] / [32] the read kernel's static work queue (next item / workgroups gone)
+  int32_t* ovf;    // control block (256 B): [0] number of 16-byte groups written (or query elements read) so far that held an element
+                   // outside fp16's window, plus the sticky error bits 1 << 30 (slot / frame count out of range) and 1 << 29 (a merge
+                   // timed out); [1] merges that timed out; [16] / [32] the read kernel's static work queue (next item / workgroups
+                   // gone).  Bytes 64.. (queue words, arrival counters) are cleared by the launcher before every read
   int32_t* cnt;    // [no][nqt_max][2] (arrived, done) counters of the partials of an (object, query tile) pair
                    // (all queue words and counters are zero between reads)
   int no, Tcap, h, w, hw, hwp;

@@ -166,6 +166,7 @@ __device__ inline int xcd_remap(int b, int n) {
 }
 
 constexpr int kLdsFloats = kDe * kKS + kDo * kVS + kJT * kPS + kQT + 4 + (kMaxT + 4);
+static_assert(kLdsFloats * 4 + 2048 <= kLdsBytesPerCU, "mr_main's LDS (tiles + the prefix array of kMaxT frames) must fit one CU");
 
 template <bool REGIONAL>
 __global__ __launch_bounds__(kThreads, 1) void mr_main(const KArgs a) {
@@ -903,6 +904,14 @@ int launch_bank_read(BankReadArgs& m, hipStream_t st) {
   // ONE kernel: bk_main writes the q_val half and the masked cells while it waits for its plan, reads, and the last
   // arriver of every (object, query tile) pair merges the pair's partials and writes the read-out (bank.hip).
   // ev_mid is kept for the callers that bracket "main" and "combine" separately: the second bracket is now empty.
+  // The read kernel's queue words and arrival counters must be zero when it starts.  Every read leaves them so, but an
+  // aborted launch (or a merge that timed out) would poison every later read of the bank: clear them per call
+  // (cdna_hip_programming.md section 6 Guideline 16, "re-initialise every call"; a memset node under graph capture).  The first
+  // 64 bytes (overflow / time-out words) are the bank's own sticky state and stay.
+  {
+    const BankView b = bank_view(m.bank, m.no, m.Tcap, m.h, m.w);
+    if (hipMemsetAsync(reinterpret_cast<char*>(b.ovf) + 64, 0, bank_ctl_bytes(m.no, m.h, m.w) - 64, st) != hipSuccess) return RMNET_E_LAUNCH;
+  }
   if (m.ev_start && hipEventRecord(m.ev_start, st) != hipSuccess) return RMNET_E_LAUNCH;
   if (int e = launch_bank_main(m, st)) return e;
   if (m.ev_mid && hipEventRecord(m.ev_mid, st) != hipSuccess) return RMNET_E_LAUNCH;

@@ -226,6 +226,20 @@ class MemoryBank:
         off = _lib.load().rmnet_bank_overflow_offset(self.no, self.capacity, self.h, self.w)
         return int(self.blob[off:off + 4].view(torch.int32).item())
 
+    def timeout_count(self):
+        """Merges of a read that gave up waiting for another workgroup's partial (the int32 behind the overflow word).  Always 0
+        on a healthy device; a non-zero value also sets a sticky bit in the overflow word.  Synchronises the stream."""
+        off = _lib.load().rmnet_bank_overflow_offset(self.no, self.capacity, self.h, self.w)
+        return int(self.blob[off + 4:off + 8].view(torch.int32).item())
+
+    def assert_synced(self):
+        """Debug aid: the host mirror ``committed`` and the device counter ``n_dev`` agree (they only move together in
+        ``commit``; a captured ``frame_step(commit=True)`` or a foreign write to either would desynchronise them silently --
+        the kernels flag an out-of-range slot in the overflow word, an in-range wrong slot only this check finds).  Synchronises."""
+        n = int(self.n_dev.item())
+        if n != self.committed:
+            raise RuntimeError('MemoryBank: device frame counter %d != host counter %d' % (n, self.committed))
+
     def stage(self, k4, v4, rects):
         """Write one frame into the first free slot without committing it (the tentative previous
         frame of models/rmnet.py:416-426).  Returns the number of frames visible to ``read``.  The slot index
@@ -246,7 +260,10 @@ class MemoryBank:
         return self.committed + 1
 
     def commit(self):
-        """Keep the staged frame: one-element add on the device counter (after the read that used it as tentative)."""
+        """Keep the staged frame: one-element add on the device counter (after the read that used it as tentative).  Not inside
+        a graph capture: the host mirror would advance once, the device counter on every replay."""
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('MemoryBank.commit() inside a HIP graph capture: commit between replays (RMNet.forward does)')
         self.committed += 1
         self.n_dev += 1
 
@@ -305,6 +322,20 @@ class TensorBank:
 
     def overflow_count(self):
         return 0
+
+    def timeout_count(self):
+        """Merges of a read that gave up waiting for another workgroup's partial (the int32 behind the overflow word).  Always 0
+        on a healthy device; a non-zero value also sets a sticky bit in the overflow word.  Synchronises the stream."""
+        off = _lib.load().rmnet_bank_overflow_offset(self.no, self.capacity, self.h, self.w)
+        return int(self.blob[off + 4:off + 8].view(torch.int32).item())
+
+    def assert_synced(self):
+        """Debug aid: the host mirror ``committed`` and the device counter ``n_dev`` agree (they only move together in
+        ``commit``; a captured ``frame_step(commit=True)`` or a foreign write to either would desynchronise them silently --
+        the kernels flag an out-of-range slot in the overflow word, an in-range wrong slot only this check finds).  Synchronises."""
+        n = int(self.n_dev.item())
+        if n != self.committed:
+            raise RuntimeError('MemoryBank: device frame counter %d != host counter %d' % (n, self.committed))
 
     def stage(self, k4, v4, rects):
         if self.committed >= self.capacity:

@@ -398,7 +398,11 @@ class RMNet(nn.Module):
                     logit[b, missing] = _ABSENT_LOGIT
                     prob = None
             est[:, t] = F.softmax(logit, dim=1) if prob is None else prob
-        if bank.overflow_count():   # (one host sync per clip) K/V outside the split-fp16 window: redo the clip exactly
+        if bank.overflow_count():   # (one host sync per clip) K / V / q_key outside the split-fp16 window: redo the clip exactly
+            if isinstance(bank, ops.MemoryBank) and bank.timeout_count():
+                import warnings
+                warnings.warn('rmnet_amd: %d merge(s) of the bank read timed out on this device (scheduling problem?); '
+                              'the clip is re-read with the exact-fp32 kernels' % bank.timeout_count())
             return self.forward(frames, masks, optical_flows, n_objects, memorize_every, device=dev, _exact=True)
         return est
 
@@ -419,7 +423,12 @@ class RMNet(nn.Module):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out = self.frame_step(ctx, bank, *bufs, commit=False)
-        except Exception as exc:                       # pragma: no cover - depends on the torch / ROCm build
+        except RuntimeError as exc:                    # pragma: no cover - depends on the torch / ROCm build
+            # only what torch raises for an unsupported / invalidated capture; anything else (a bug in frame_step) propagates.
+            # The eager warm-up above ran first: a failure there is not a capture problem and is re-raised.
+            torch.cuda.synchronize(dev)                # leave the stream / allocator in a defined state before going on eagerly
+            if 'captur' not in str(exc).lower() and 'graph' not in str(exc).lower():
+                raise
             import warnings
             warnings.warn('rmnet_amd: HIP graph capture of the frame step failed (%s); running eagerly' % (exc,))
             return None
