@@ -471,9 +471,35 @@ def main():
     torch.cuda.synchronize()
     rd.barrier()
     torch.cuda.synchronize()
-    elapsed = rd.max_over_ranks(time.perf_counter() - t0)
+    elapsed_local = time.perf_counter() - t0
+    elapsed = rd.max_over_ranks(elapsed_local)
     assert bool(torch.isfinite(out).all())
     _phase('timed region done')
+    multi = None
+    if world > 1:
+        # Outside the timed region: every rank's own rate, and the path's ONE collective step -- the gather of the per-clip
+        # label maps to rank 0 (rmnet_amd.dist.gather_label_maps: header all_gather + one padded gather) -- timed
+        # on the last frame's label maps (uint8 [1, H, W] per clip), payloads resident on the GPU.
+        import torch.distributed as tdist
+        times = [None] * world
+        tdist.all_gather_object(times, float(elapsed_local))
+        labels = out.argmax(dim=1).to(torch.uint8)
+        mine = {rank * B + c: labels[c:c + 1] for c in range(B)}
+        rd.gather_label_maps(mine, world * B)                           # warm-up (connection set-up)
+        torch.cuda.synchronize()
+        rd.barrier()
+        tg = time.perf_counter()
+        got = rd.gather_label_maps(mine, world * B)
+        torch.cuda.synchronize()
+        gather_ms = rd.max_over_ranks(1e3 * (time.perf_counter() - tg))
+        if rank == 0:
+            assert sorted(got) == list(range(world * B)) and tuple(got[0].shape) == (1, H, W)
+        multi = {'per_rank_fps': [round(B * args.steps / t, 2) for t in times],
+                 'gather_ms': round(gather_ms, 3), 'gather_bytes_per_rank': int(B * H * W),
+                 'backend': tdist.get_backend(),
+                 'note': 'per_rank_fps = clips x steps / that rank\'s own time of the timed region (value uses the max over ranks); '
+                         'gather_ms = header all_gather + one padded gather of the last frame\'s uint8 label maps to rank 0, '
+                         'outside the timed region (a whole clip moves N x as many bytes, once per clip)'}
     if args.graph:
         # events cannot be read back from inside a replayed graph: time the kernel on the same state
         # with an eager pass right after the timed region
@@ -534,6 +560,39 @@ def main():
     extras = None
     if rank == 0 and world == 1 and not args.no_extras:
         extras = {}
+        # ---- who owns the timed region's GPU time: hand-written kernels (namespace rmnet) vs everything else (MIOpen / rocBLAS /
+        #      torch element-wise), from torch.profiler's device-side kernel records of three steps of the same loop
+        try:
+            from torch.profiler import ProfilerActivity, profile
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                for i in range(3):
+                    eager_step(i)
+                torch.cuda.synchronize()
+            own = other = conv = 0.0
+            top = {}
+            for evt in prof.key_averages():
+                dt_us = float(getattr(evt, 'device_time_total', 0.0) or getattr(evt, 'cuda_time_total', 0.0))
+                if dt_us <= 0.0:
+                    continue
+                name = evt.key
+                if 'rmnet' in name:
+                    own += dt_us
+                else:
+                    other += dt_us
+                    if any(k in name.lower() for k in ('conv', 'winograd', 'gemm', 'igemm', 'miopen', 'cijk', 'sp3asm', 'naive_conv')):
+                        conv += dt_us
+                top[name] = top.get(name, 0.0) + dt_us
+            tot = own + other
+            if tot > 0:
+                big = sorted(top.items(), key=lambda kv: -kv[1])[:3]
+                extras['timed_region_gpu_time_share'] = {
+                    'hand_written_rmnet_kernels': round(own / tot, 4), 'convolution_gemm_kernels': round(conv / tot, 4),
+                    'other_torch_kernels': round((other - conv) / tot, 4), 'gpu_busy_ms_per_step': round(tot / 3e3, 3),
+                    'largest_kernels': [{'name': k[:80], 'share': round(v / tot, 4)} for k, v in big],
+                    'note': 'torch.profiler device records of 3 steps (8 clips per GPU); box-to-box variance of the headline value '
+                            'follows the convolution share (MIOpen solver choice), not the hand-written kernels'}
+        except Exception as exc:                          # (profiler support depends on the torch / ROCm build)
+            extras['timed_region_gpu_time_share'] = {'error': repr(exc)[:200]}
         _phase('extras: single stream')
         # ---- one clip alone (single stream): same step, B = 1
         ctx1 = net._ClipContext(net, 1, K_CH, H, W, [K_CH - 1], dev)
@@ -711,6 +770,12 @@ def main():
                         "f16 = opt-in RMNET_BANK_F16: fp16 operands, fp32 accumulate, read-out error ~2^-11 of the values (3e-4 worst, 5e-6 "
                         "typical), whole-clip mask IoU vs the CPU path 1.0000 for this workload, >= 0.9985 for 3-5 objects on random-init "
                         "weights (tests/test_gpu_parity.py, extras.free_running.f16_vs_split)" % args.read_precision}
+        if extras is not None and extras.get('single_stream_fps'):
+            line['config']['workload'] += ' -- value = %d clips batched per GPU; ONE 480p stream alone: %.1f frames/s' % (B, extras['single_stream_fps'])
+        else:
+            line['config']['workload'] += ' -- value = %d clips batched per GPU' % B
+        if multi is not None:
+            line['multi_gpu'] = multi
         if extras is not None:
             line['extras'] = extras
         if world == 1 and not args.no_cpu_baseline:

@@ -830,10 +830,16 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float x = qb[(size_t)(32 * ks + 8 * g + e) * b.hw] * keep;
+#ifndef BK_NO_QOVER
         qover |= !(fabsf(x) <= 65504.0f);
         qh[ks][e] = (_Float16)fminf(fmaxf(x, -65504.0f), 65504.0f);
+#else
+        qh[ks][e] = (_Float16)x;
+#endif
       }
+#ifndef BK_NO_QOVER
     if (qover && qvalid) atomicAdd(b.ovf, 1);   // (as in the split mode)
+#endif
   }
   float mref = -INFINITY, lsum = 0.0f;
   half8 ones;
@@ -995,7 +1001,7 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
   PfRegs pf_pro[BK_PF > 1 ? BK_PF - 1 : 1], pf_a, pf_b;
   if (BK_PF && BK_PF_DMA) {
 #pragma unroll 1
-    for (int s_ = 1; s_ < BK_PF; ++s_) prefetch_dma(s_);
+    for (int s_ = 1; s_ < BK_PF; ++s_) prefetch_dma(s_);   // (step 0 and the K tiles of steps 1..4 are demand loads of the prologue)
   } else if (BK_PF) {
 #pragma unroll
     for (int s_ = 1; s_ < BK_PF; ++s_) prefetch_step(s_, pf_pro[s_ - 1]);   // (step 0 and the K tiles of steps 1..4 are demand loads of the prologue)
@@ -1311,22 +1317,34 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
 #endif
   const int ng = a.nobj;
   const int hw = b.hw;
+  // The frame count may live on the device (graph replay): its load, the areas of the first 64 slots and the query
+  // rectangles are requested TOGETHER -- one memory round trip in front of the plan instead of two dependent ones
+  // (inside the frame loop all three miss every cache).
+  const int lane0 = tid & 63;
+  int spec_ar = 0;
+  if (a.nobj <= kProducers + kConsumers && wave < a.nobj && lane0 < b.Tcap)
+    spec_ar = b.area[(size_t)(a.obj0 + wave) * b.Tcap + lane0];
   const int T_raw = a.T + (a.T_dev ? __builtin_amdgcn_readfirstlane(*a.T_dev) : 0);
   const int T_ = min(max(T_raw, 1), b.Tcap);         // memorised frames to read (the clamp is memory safety only:
+#ifndef BK_NO_TFLAG
   if (T_raw != T_ && blockIdx.x == 0 && tid == 0) atomicOr(b.ovf, kBankBadSlot);   // an out-of-range count is flagged)
+#endif
   int* q_head = b.ovf + 16;                        // control block of the bank: static work queue (next item) ...
   int* q_exit = b.ovf + 32;                        // ... workgroups that have left the kernel (the last one zeroes both)
 
   // ---- launch-wide plan, computed identically by every workgroup from the device-resident boxes
   //      (no host sync)
-  const int lane0 = tid & 63;
   // Fast path (<= 12 objects, <= 64 memorised frames): wave w owns object w, lane t its frame t; the
   // areas stay in registers, so the owner wave later builds the object's tile prefix without a
   // second trip to memory.  Otherwise: LDS atomics now, a reload of the object's areas later.
   const bool fastplan = ng <= kProducers + kConsumers && T_ <= RMNET_WAVE;
   int my_ar = 0;
   if (fastplan) {
+#ifdef BK_NO_SPEC
     if (wave < ng && lane0 < T_) my_ar = b.area[(size_t)(a.obj0 + wave) * b.Tcap + lane0];
+#else
+    if (wave < ng && lane0 < T_) my_ar = spec_ar;
+#endif
   } else if (tid < ng) {
     o_njt[tid] = 0; o_m[tid] = 0;
   }
@@ -1550,6 +1568,9 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
           __builtin_amdgcn_s_sleep(4);
           if (++polls > (1 << 22)) { gave_up = true; break; }
         }
+#ifdef BK_NO_TMO
+        gave_up = false;
+#endif
         if (gave_up) {   // (cannot happen: the others hold a ticket and only store.  Never hang the GPU: count it in the time-out
           atomicAdd(b.ovf + 1, 1);                                          // word, make the bank say "do not trust me" and leave
           atomicOr(b.ovf, kBankTimeout);                                    // the counters alone -- late arrivers may still bump them;

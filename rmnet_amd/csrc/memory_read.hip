@@ -908,10 +908,12 @@ int launch_bank_read(BankReadArgs& m, hipStream_t st) {
   // aborted launch (or a merge that timed out) would poison every later read of the bank: clear them per call
   // (cdna_hip_programming.md section 6 Guideline 16, "re-initialise every call"; a memset node under graph capture).  The first
   // 64 bytes (overflow / time-out words) are the bank's own sticky state and stay.
+#ifndef RMNET_NO_CTL_MEMSET
   {
     const BankView b = bank_view(m.bank, m.no, m.Tcap, m.h, m.w);
     if (hipMemsetAsync(reinterpret_cast<char*>(b.ovf) + 64, 0, bank_ctl_bytes(m.no, m.h, m.w) - 64, st) != hipSuccess) return RMNET_E_LAUNCH;
   }
+#endif
   if (m.ev_start && hipEventRecord(m.ev_start, st) != hipSuccess) return RMNET_E_LAUNCH;
   if (int e = launch_bank_main(m, st)) return e;
   if (m.ev_mid && hipEventRecord(m.ev_mid, st) != hipSuccess) return RMNET_E_LAUNCH;

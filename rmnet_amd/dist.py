@@ -101,7 +101,10 @@ def gather_label_maps(results, n_videos, dst=0):
         return dict(results)
     rank, world = dist.get_rank(), dist.get_world_size()
     on_gpu = dist.get_backend() == 'nccl'
-    dev = torch.device('cuda', torch.cuda.current_device()) if on_gpu else torch.device('cpu')
+    dev = torch.device('cuda', torch.cuda.current_device()) if on_gpu else torch.device('cpu')      # where the collectives run
+    # where the payload is PACKED: on the GPU whenever the label maps live there (one flat buffer, one D2H copy for gloo,
+    # none for RCCL) -- the same packing code under both backends
+    pack_dev = next((t.device for t in results.values() if t.is_cuda), dev)
     header = torch.zeros(n_videos, 4, dtype=torch.int64)
     for v, t in results.items():
         header[v] = torch.tensor([1, t.shape[0], t.shape[1], t.shape[2]], dtype=torch.int64)
@@ -111,12 +114,13 @@ def gather_label_maps(results, n_videos, dst=0):
     table = torch.stack(headers).cpu()                               # [world, n_videos, 4], one D2H copy
     sizes = (table[:, :, 0] * table[:, :, 1] * table[:, :, 2] * table[:, :, 3]).sum(dim=1).tolist()
     cap = max(max(sizes), 1)
-    payload = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    payload = torch.zeros(cap, dtype=torch.uint8, device=pack_dev)
     at = 0
     for v in sorted(results):
-        flat = results[v].to(dev).reshape(-1)
+        flat = results[v].to(pack_dev).reshape(-1)
         payload[at:at + flat.numel()] = flat
         at += flat.numel()
+    payload = payload.to(dev)
     payloads = [torch.zeros_like(payload) for _ in range(world)] if rank == dst else None
     dist.gather(payload, payloads, dst=dst)
     out = {}
