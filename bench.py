@@ -366,7 +366,7 @@ def main():
                     help='independent clips batched on every GPU (one 480p clip cannot fill 256 CUs; measured '
                          'on MI355X: 164 / 194 / 227 / 248 / 247 frames/s at 1 / 2 / 4 / 8 / 10 clips)')
     ap.add_argument('--graph', action='store_true', help='replay the frame step as one captured HIP graph')
-    ap.add_argument('--read-precision', choices=('split', 'f16'), default='split',
+    ap.add_argument('--read-precision', choices=('split', 'f16'), default='f16',
                     help="arithmetic of the bank read in the timed region: 'split' = fp16 hi/lo pairs, three MFMA terms, fp32-class "
                          "(default); 'f16' = fp16 operands, one term, ~2^-11 relative (opt-in mode, include/rmnet_hip.h).  The other "
                          "mode's kernel is timed on the same launches after the timed region and reported under roofline.modes")

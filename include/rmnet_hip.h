@@ -25,8 +25,9 @@
 extern "C" {
 #endif
 
-#define RMNET_ABI_VERSION 3   /* 2: rmnet_bank_read_f32 takes a mutable bank; rmnet_bank_area_offset.  3: RMNET_MR_F16 / RMNET_BANK_F16,
-                               * rmnet_bank_read_f32_at takes flags */
+#define RMNET_ABI_VERSION 4   /* 2: rmnet_bank_read_f32 takes a mutable bank; rmnet_bank_area_offset.  3: RMNET_MR_F16 / RMNET_BANK_F16,
+                               * rmnet_bank_read_f32_at takes flags.  4: banks of any Tcap, chunked reads of T > 2048 (rmnet_bank_read_workspace_bytes_for);
+                               * the read counts out-of-window query elements; sticky error bits + time-out word behind the overflow word */
 
 enum {
   RMNET_OK = 0,
@@ -174,7 +175,10 @@ int rmnet_memory_read_f32_ev(const float *m_key, const float *m_val, const float
  *       a healthy device; the int32 right behind the overflow word counts these time-outs separately).  Any non-zero value means:
  *       do not trust the reads of this bank, re-run exactly.
  *       rmnet_bank_area_offset(): byte offset of the int32 [no][Tcap] table of cells stored per slot (accounting).
- *       Tcap <= 2048.
+ *       One launch reads at most 2048 slots (LDS prefix arrays).  Longer memories (models/rmnet.py:416-426 has no bound; ABI v4):
+ *       a bank may have any Tcap; rmnet_bank_read_f32 / _at with T > 2048 (host-side T only: T_dev must be NULL for such a bank)
+ *       read it in chunks of 2048 slots and merge the chunks' read-outs by their soft-max state (m, l) -- the same merge the
+ *       kernel applies to the partial results of one launch -- in a workspace of rmnet_bank_read_workspace_bytes_for(...) bytes.
  * rmnet_bank_read_f32_at(..., flags): 0 = the arithmetic above; RMNET_BANK_F16 = hi planes only (see RMNET_MR_F16: fp16
  *       operands, fp32 accumulate, ~2^-11 relative, 1.5-2x as fast).  The bank is the same either way: a clip
  *       can be memorised once and read in both modes.
@@ -195,7 +199,9 @@ int rmnet_bank_read_f32_at(void *bank, int no, int Tcap, int h, int w, int T, co
                            const float *q_key, const float *q_val, const int32_t *qry_rects,
                            float *mem_val, void *workspace, size_t workspace_bytes, void *stream,
                            void *ev_start, void *ev_mid, void *ev_end);
+/* workspace of a read: the first form covers T <= 2048 frames, the _T form any T (ABI v4, chunked reads) */
 size_t rmnet_bank_read_workspace_bytes(int no, int h, int w);
+size_t rmnet_bank_read_workspace_bytes_for(int no, int h, int w, int T);
 int rmnet_bank_read_f32(void *bank, int no, int Tcap, int h, int w, int T,
                         const float *q_key, const float *q_val, const int32_t *qry_rects,
                         float *mem_val, void *workspace, size_t workspace_bytes, void *stream,

@@ -55,6 +55,7 @@ SIGNATURES = {
         c_f32p, c_i32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_void_p]),
     'rmnet_bank_read_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 3),
+    'rmnet_bank_read_workspace_bytes_for': (ctypes.c_size_t, [ctypes.c_int] * 4),
     'rmnet_bank_read_f32': (ctypes.c_int, [
         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p,
         c_f32p, c_i32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
@@ -81,7 +82,7 @@ SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lib = None
 
 

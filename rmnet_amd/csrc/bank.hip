@@ -303,6 +303,9 @@ struct BArgs {
   int gate;                  // != 0: do nothing when the bank's overflow word is set (mr_main then runs instead)
   int obj0, nobj;            // objects [obj0, obj0 + nobj) belong to this launch (nobj <= kMaxObj)
   int slot0, target;         // first partial slot of the launch; workgroups to aim for
+  int Tmax;                  // frames readable through this view (<= kMaxT; the view may start at a later slot of a longer bank)
+  float* ml_out;             // optional [no][2][h*w]: the soft-max state (reference m in the log2 domain, sum l) of every query cell
+                             // that went through a merge -- lets the launcher chain reads of more than kMaxT frames (bk_chain)
   float qscale;              // log2(e) / sqrt(De) * 2^6, folded into the query fragments
 };
 
@@ -1322,10 +1325,10 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   // (inside the frame loop all three miss every cache).
   const int lane0 = tid & 63;
   int spec_ar = 0;
-  if (a.nobj <= kProducers + kConsumers && wave < a.nobj && lane0 < b.Tcap)
+  if (a.nobj <= kProducers + kConsumers && wave < a.nobj && lane0 < a.Tmax)
     spec_ar = b.area[(size_t)(a.obj0 + wave) * b.Tcap + lane0];
   const int T_raw = a.T + (a.T_dev ? __builtin_amdgcn_readfirstlane(*a.T_dev) : 0);
-  const int T_ = min(max(T_raw, 1), b.Tcap);         // memorised frames to read (the clamp is memory safety only:
+  const int T_ = min(max(T_raw, 1), a.Tmax);         // memorised frames to read (the clamp is memory safety only:
 #ifndef BK_NO_TFLAG
   if (T_raw != T_ && blockIdx.x == 0 && tid == 0) atomicOr(b.ovf, kBankBadSlot);   // an out-of-range count is flagged)
 #endif
@@ -1372,6 +1375,9 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     }
   }
   __syncthreads();
+#if BK_CLK
+  const long long t_loads = (long long)__builtin_amdgcn_s_memrealtime() - t_real;   // areas / rectangles in LDS
+#endif
   if (tid < RMNET_WAVE) {   // one wave, lane = object
     const int nqt = tid < ng ? o_nqt[tid] : 0, njt = tid < ng ? o_njt[tid] : 0;
     const int W = wave_sum(nqt * njt), njt_max = wave_max(njt);
@@ -1408,7 +1414,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   const int nchunks = sld(plan_n), C = sld(plan_c);
 #if BK_CLK
   long long* clk_rec = reinterpret_cast<long long*>(a.ws_plan + (size_t)(a.obj0 + a.nobj) * kPlanInts + 16) + 8 * blockIdx.x;
-  if (tid == 0) { clk_rec[4] = (long long)__builtin_amdgcn_s_memrealtime() - t_real; clk_rec[5] = 0; clk_rec[6] = 0; }   // plan done
+  if (tid == 0) { clk_rec[4] = (long long)__builtin_amdgcn_s_memrealtime() - t_real; clk_rec[5] = 0; clk_rec[6] = 0; clk_rec[7] = t_loads; }   // plan done
 #endif
   if ((int)blockIdx.x < ng && tid == 0) {   // plan record of object blockIdx.x (tools / debugging only)
     const int og = blockIdx.x;
@@ -1625,10 +1631,12 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
       red[sl * kQT + qi] = mloc;
     }
     __syncthreads();                                                                // E3
+    float mtot_q = 0.0f;                                   // (producers) the pair's reference of query ln
     if (producer) {
       const int qi = ln, sl = wave;
       float mtot = fmaxf(fmaxf(red[qi], red[kQT + qi]), fmaxf(red[2 * kQT + qi], red[3 * kQT + qi]));
       if (n_out > 0.0f) mtot = fmaxf(mtot, 0.0f);          // the masked memory cells have S = 0
+      mtot_q = mtot;
       float lloc = 0.0f;
 #pragma unroll
       for (int j = 0; j < kMl; ++j) {
@@ -1648,6 +1656,16 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
       red2[sl * kQT + qi] = lloc + (sl == 0 && n_out > 0.0f ? n_out * __builtin_amdgcn_exp2f(-mtot) : 0.0f);
     }
     __syncthreads();                                                                // E4
+    if (a.ml_out && wave == 0) {        // chained reads (> kMaxT frames): the state of this pair's queries
+      const int nq = wk.qt * kQT + ln;
+      if (nq < wk.Mq) {
+        const int rw = wk.qr.width(), ry = nq / rw;
+        const int cell = (wk.qr.cy0 + ry) * b.w + wk.qr.cx0 + (nq - ry * rw);
+        float* ml = a.ml_out + (size_t)wk.o * 2 * hw;
+        ml[cell] = mtot_q;
+        ml[hw + cell] = red2[ln] + red2[kQT + ln] + red2[2 * kQT + ln] + red2[3 * kQT + ln];
+      }
+    }
     if (!producer) {
       // ---- consumers: O = (own x w_self + sum_s partial_s x w_s) / l_tot for this wave's 64 channels x 64 queries
       float wq[4], iq[4];
@@ -1988,6 +2006,59 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
 
 }  // namespace
 
+// ---- reads of more than kMaxT memorised frames (models/rmnet.py:416-426 has no bound): the launcher reads the bank in
+// chunks of <= kMaxT slots -- every chunk is an ordinary bk_main launch that also leaves the soft-max state (m, l) of its
+// query cells -- and bk_chain merges the chunks' read-outs exactly as the last arriver merges the partials of a pair:
+//     out = sum_c w_c out_c / sum_c w_c,   w_c = l_c 2^(m_c - max_c m_c).
+// A cell that went through no merge (outside the query box, or no memory cell inside any box of the chunk) was written by
+// the static part with the mean of the chunk's values: all its logits are 0, i.e. m = 0 and l = T_c h w -- the state the
+// launcher pre-fills (bk_ml_fill).
+namespace {
+__global__ __launch_bounds__(256) void bk_ml_fill(float* ml, int no, int hw, float l0) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < no * 2 * hw) ml[i] = ((i / hw) & 1) ? l0 : 0.0f;
+}
+constexpr int kChainMax = 64;
+struct ChainArgs { float* out; const float* tmp; const float* ml; int no, hw, nchunk; };
+// grid (ceil(hw / 256), no): thread = one query cell, all 512 read-out channels (coalesced over the cells)
+__global__ __launch_bounds__(256) void bk_chain(const ChainArgs c) {
+  const int cell = blockIdx.x * 256 + threadIdx.x, o = blockIdx.y;
+  if (cell >= c.hw) return;
+  float wgt[kChainMax];
+  float mmax = -INFINITY;
+  for (int k = 0; k < c.nchunk; ++k) mmax = fmaxf(mmax, c.ml[((size_t)(k * c.no + o) * 2) * c.hw + cell]);
+  float lsum = 0.0f;
+  for (int k = 0; k < c.nchunk; ++k) {
+    const float* ml = c.ml + ((size_t)(k * c.no + o) * 2) * c.hw;
+    wgt[k] = ml[c.hw + cell] * __builtin_amdgcn_exp2f(ml[cell] - mmax);
+    lsum += wgt[k];
+  }
+  const float inv = 1.0f / lsum;
+  float* dst = c.out + (size_t)o * 2 * kDo * c.hw + cell;
+  for (int d = 0; d < kDo; ++d) {
+    float acc = wgt[0] * dst[(size_t)d * c.hw];
+    for (int k = 1; k < c.nchunk; ++k)
+      acc += wgt[k] * c.tmp[((size_t)((k - 1) * c.no + o) * 2 * kDo + d) * c.hw + cell];   // (a chunk's whole [no][2 Do][hw] output)
+    dst[(size_t)d * c.hw] = acc * inv;
+  }
+}
+}  // namespace
+
+int bank_chain_max_chunks() { return kChainMax; }
+int bank_max_frames_per_launch() { return kMaxT; }
+
+int launch_bank_ml_fill(float* ml, int no, int hw, float l0, hipStream_t st) {
+  hipLaunchKernelGGL(bk_ml_fill, dim3((no * 2 * hw + 255) / 256), dim3(256), 0, st, ml, no, hw, l0);
+  return check_launch();
+}
+
+int launch_bank_chain(float* out, const float* tmp, const float* ml, int no, int hw, int nchunk, hipStream_t st) {
+  if (nchunk < 2 || nchunk > kChainMax) return RMNET_E_UNSUPPORTED;
+  ChainArgs c{out, tmp, ml, no, hw, nchunk};
+  hipLaunchKernelGGL(bk_chain, dim3((hw + 255) / 256, no), dim3(256), 0, st, c);
+  return check_launch();
+}
+
 int launch_bank_append(void* bank, int no, int Tcap, int h, int w, int slot, const float* k4,
                        const float* v4, const int32_t* rects, hipStream_t st, const int32_t* slot_dev) {
   const long long hw = (long long)h * w;
@@ -2000,7 +2071,7 @@ int launch_bank_stage(void* bank, int no, int Tcap, int h, int w, int slot0, int
   if (!bank || !k4 || !v4 || no <= 0 || Tcap <= 0 || h <= 0 || w <= 0 || nf <= 0 || slot0 < 0 ||
       slot0 + nf > Tcap)
     return RMNET_E_INVALID_ARG;
-  if ((long long)no * nf > 65535 || Tcap > kMaxT) return RMNET_E_UNSUPPORTED;
+  if ((long long)no * nf > 65535) return RMNET_E_UNSUPPORTED;
   const BankView b = bank_view(bank, no, Tcap, h, w);
   hipLaunchKernelGGL(bk_append, dim3(b.hwp / kJT, no * nf, 1 + kDo / kDe), dim3(kThreads), 0, st, b, slot0, slot_dev, nf,
                      k4, v4, k_cs, k_os, v_cs, v_os, rects);
@@ -2014,6 +2085,18 @@ size_t bank_overflow_offset(int no, int Tcap, int h, int w) { return bank_bytes(
 int launch_bank_main(const BankReadArgs& m, hipStream_t st) {
   BArgs a;
   a.b = bank_view(m.bank, m.no, m.Tcap, m.h, m.w);
+  if (m.t0 < 0 || m.t0 >= m.Tcap) return RMNET_E_INVALID_ARG;
+  if (m.t0 > 0) {   // a read of slots [t0, ...): the same view with every per-slot array advanced by t0 slots (object stride = Tcap)
+    a.b.kh += (size_t)m.t0 * a.b.hwp * kDe * sizeof(_Float16);
+    a.b.kl += (size_t)m.t0 * a.b.hwp * kDe * sizeof(_Float16);
+    a.b.vh += (size_t)m.t0 * kDo * a.b.hwp * sizeof(_Float16);
+    a.b.vl += (size_t)m.t0 * kDo * a.b.hwp * sizeof(_Float16);
+    a.b.vpart += (size_t)m.t0 * (a.b.hwp / kJT) * kDo;
+    a.b.colsum += (size_t)m.t0 * kDo;
+    a.b.area += m.t0;
+  }
+  a.Tmax = m.Tcap - m.t0 < kMaxT ? m.Tcap - m.t0 : kMaxT;
+  a.ml_out = m.ml_out;
   a.qk = m.qk; a.qv = m.qv; a.qry_rects = m.qry_rects;
   a.out = m.out;
   a.ws_o = m.ws_o; a.ws_ml = m.ws_ml; a.ws_plan = m.ws_plan;

@@ -107,6 +107,11 @@ size_t rmnet_bank_read_workspace_bytes(int no, int h, int w) {
   return bank_read_ws_bytes(no, h, w);
 }
 
+size_t rmnet_bank_read_workspace_bytes_for(int no, int h, int w, int T) {
+  if (no <= 0 || h <= 0 || w <= 0 || T <= 0) return 0;
+  return bank_read_ws_bytes_T(no, h, w, T);
+}
+
 int rmnet_bank_read_f32(void* bank, int no, int Tcap, int h, int w, int T, const float* q_key,
                         const float* q_val, const int32_t* qry_rects, float* mem_val,
                         void* workspace, size_t workspace_bytes, void* stream, void* ev_start,

@@ -234,7 +234,14 @@ struct BankReadArgs {
   int gate = 0;               // != 0: bk_main returns at once when the bank's overflow word is set
   const int32_t* T_dev = nullptr;   // optional device-resident frame counter added to T
   int f16 = 0;                // != 0: fp16-operand mode (hi planes only, one MFMA term)
+  int t0 = 0;                 // first slot read (chunked reads of a bank longer than one launch can take)
+  float* ml_out = nullptr;    // optional [no][2][h*w]: soft-max state of the merged query cells (bank.hip: bk_chain)
 };
+int bank_max_frames_per_launch();
+int bank_chain_max_chunks();
+int launch_bank_ml_fill(float* ml, int no, int hw, float l0, hipStream_t st);
+int launch_bank_chain(float* out, const float* tmp, const float* ml, int no, int hw, int nchunk, hipStream_t st);
+size_t bank_read_ws_bytes_T(int no, int h, int w, int T);
 int launch_bank_append(void* bank, int no, int Tcap, int h, int w, int slot, const float* k4,
                        const float* v4, const int32_t* rects, hipStream_t st, const int32_t* slot_dev = nullptr);
 int launch_bank_stage(void* bank, int no, int Tcap, int h, int w, int slot0, int nf, const float* k4,

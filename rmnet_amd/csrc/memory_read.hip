@@ -889,33 +889,69 @@ size_t bank_read_ws_bytes(int no, int h, int w) {
       ;
 }
 
-int launch_bank_read(BankReadArgs& m, hipStream_t st) {
-  if (!m.bank || !m.qk || !m.qv || !m.out) return RMNET_E_INVALID_ARG;
-  if (m.no <= 0 || m.Tcap <= 0 || m.h <= 0 || m.w <= 0 || m.T > m.Tcap || (m.T <= 0 && !m.T_dev) || m.T < 0)
-    return RMNET_E_INVALID_ARG;
-  if (m.no > 65535 || m.Tcap > kMaxT) return RMNET_E_UNSUPPORTED;
-  if (!m.ws || m.ws_bytes < bank_read_ws_bytes(m.no, m.h, m.w)) return RMNET_E_WORKSPACE;
+size_t bank_read_ws_bytes_T(int no, int h, int w, int T) {
+  const size_t one = bank_read_ws_bytes(no, h, w);
+  const int per = bank_max_frames_per_launch();
+  if (T <= per) return one;
+  const size_t nchunk = ((size_t)T + per - 1) / per, hw = (size_t)h * w;
+  return one + align256((nchunk - 1) * no * 2 * kDo * hw * 4) + align256(nchunk * no * 2 * hw * 4);
+}
+
+static int bank_read_one(BankReadArgs& m, hipStream_t st) {
   const int hw = m.h * m.w;
   const size_t tslots = bank_total_slots(m.no, hw);
   m.slots = (int)tslots;
   m.ws_o = static_cast<float*>(m.ws);
   m.ws_ml = reinterpret_cast<float*>(static_cast<char*>(m.ws) + align256(tslots * kDo * kQT * 4));
   m.ws_plan = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(m.ws_ml) + align256(tslots * 2 * kQT * 4));
-  // ONE kernel: bk_main writes the q_val half and the masked cells while it waits for its plan, reads, and the last
-  // arriver of every (object, query tile) pair merges the pair's partials and writes the read-out (bank.hip).
-  // ev_mid is kept for the callers that bracket "main" and "combine" separately: the second bracket is now empty.
+  return launch_bank_main(m, st);
+}
+
+int launch_bank_read(BankReadArgs& m, hipStream_t st) {
+  if (!m.bank || !m.qk || !m.qv || !m.out) return RMNET_E_INVALID_ARG;
+  if (m.no <= 0 || m.Tcap <= 0 || m.h <= 0 || m.w <= 0 || m.T > m.Tcap || (m.T <= 0 && !m.T_dev) || m.T < 0)
+    return RMNET_E_INVALID_ARG;
+  if (m.no > 65535) return RMNET_E_UNSUPPORTED;
+  const int per = bank_max_frames_per_launch();
+  // a frame count that lives on the device cannot be chunked by the host: such banks hold at most one launch's frames
+  if (m.T_dev && m.Tcap > per) return RMNET_E_UNSUPPORTED;
+  if (!m.ws || m.ws_bytes < bank_read_ws_bytes_T(m.no, m.h, m.w, m.T)) return RMNET_E_WORKSPACE;
   // The read kernel's queue words and arrival counters must be zero when it starts.  Every read leaves them so, but an
   // aborted launch (or a merge that timed out) would poison every later read of the bank: clear them per call
   // (cdna_hip_programming.md section 6 Guideline 16, "re-initialise every call"; a memset node under graph capture).  The first
   // 64 bytes (overflow / time-out words) are the bank's own sticky state and stay.
+  const BankView b = bank_view(m.bank, m.no, m.Tcap, m.h, m.w);
 #ifndef RMNET_NO_CTL_MEMSET
-  {
-    const BankView b = bank_view(m.bank, m.no, m.Tcap, m.h, m.w);
-    if (hipMemsetAsync(reinterpret_cast<char*>(b.ovf) + 64, 0, bank_ctl_bytes(m.no, m.h, m.w) - 64, st) != hipSuccess) return RMNET_E_LAUNCH;
-  }
+  if (hipMemsetAsync(reinterpret_cast<char*>(b.ovf) + 64, 0, bank_ctl_bytes(m.no, m.h, m.w) - 64, st) != hipSuccess) return RMNET_E_LAUNCH;
 #endif
+  // ONE kernel: bk_main writes the q_val half and the masked cells while it waits for its plan, reads, and the last
+  // arriver of every (object, query tile) pair merges the pair's partials and writes the read-out (bank.hip).
+  // ev_mid is kept for the callers that bracket "main" and "combine" separately: the second bracket is now empty.
   if (m.ev_start && hipEventRecord(m.ev_start, st) != hipSuccess) return RMNET_E_LAUNCH;
-  if (int e = launch_bank_main(m, st)) return e;
+  if (m.T <= per) {
+    if (int e = bank_read_one(m, st)) return e;
+  } else {
+    // more memorised frames than one launch takes (LDS prefix arrays): chunks of `per` slots, merged by bk_chain (bank.hip)
+    const int nchunk = (m.T + per - 1) / per, hw = m.h * m.w;
+    if (nchunk > bank_chain_max_chunks()) return RMNET_E_UNSUPPORTED;
+    char* extra = static_cast<char*>(m.ws) + bank_read_ws_bytes(m.no, m.h, m.w);
+    float* tmp = reinterpret_cast<float*>(extra);
+    float* ml = reinterpret_cast<float*>(extra + align256((size_t)(nchunk - 1) * m.no * 2 * kDo * hw * 4));
+    float* const out = m.out;
+    const int T = m.T;
+    for (int c = 0; c < nchunk; ++c) {
+      BankReadArgs r = m;
+      r.ev_start = r.ev_mid = r.ev_end = nullptr;
+      r.t0 = c * per;
+      r.T = T - r.t0 < per ? T - r.t0 : per;
+      r.out = c == 0 ? out : tmp + (size_t)(c - 1) * m.no * 2 * kDo * hw;
+      r.ml_out = ml + (size_t)c * m.no * 2 * hw;
+      if (int e = launch_bank_ml_fill(r.ml_out, m.no, hw, (float)r.T * (float)hw, st)) return e;
+      if (c > 0 && hipMemsetAsync(reinterpret_cast<char*>(b.ovf) + 64, 0, bank_ctl_bytes(m.no, m.h, m.w) - 64, st) != hipSuccess) return RMNET_E_LAUNCH;
+      if (int e = bank_read_one(r, st)) return e;
+    }
+    if (int e = launch_bank_chain(out, tmp, ml, m.no, hw, nchunk, st)) return e;
+  }
   if (m.ev_mid && hipEventRecord(m.ev_mid, st) != hipSuccess) return RMNET_E_LAUNCH;
   if (m.ev_end && hipEventRecord(m.ev_end, st) != hipSuccess) return RMNET_E_LAUNCH;
   return RMNET_OK;

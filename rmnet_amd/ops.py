@@ -17,7 +17,7 @@ from . import _lib
 
 MR_FORCE_GENERIC = 1     # include/rmnet_hip.h RMNET_MR_*
 MR_EXACT_FP32 = 2
-BANK_MAX_SLOTS = 2048    # csrc/bank.hip, csrc/memory_read.hip kMaxT
+BANK_MAX_SLOTS = 2048    # csrc/bank.hip, csrc/memory_read.hip kMaxT: frames per LAUNCH (longer banks are read in chunks)
 
 
 def _check(t, name, dtype=torch.float32):
@@ -269,7 +269,10 @@ class MemoryBank:
 
     def read_staged(self, q_key, q_val, qry_rects=None, out=None, events=None, ws=None):
         """``read(committed + 1, ...)`` with the frame count taken from the device counter (committed frames + the
-        staged one): the call a captured graph replays."""
+        staged one): the call a captured graph replays.  A bank of more than 2048 slots is read in chunks planned on the
+        host (csrc/memory_read.hip: launch_bank_read), so there the host's own count is used."""
+        if self.capacity > BANK_MAX_SLOTS:
+            return self.read(self.committed + 1, q_key, q_val, qry_rects, out=out, events=events, ws=ws)
         return self.read(1, q_key, q_val, qry_rects, out=out, events=events, ws=ws, _t_dev=self.n_dev)
 
     def read(self, T, q_key, q_val, qry_rects=None, out=None, events=None, ws=None, _t_dev=None):
@@ -286,7 +289,7 @@ class MemoryBank:
             if out is None:
                 out = torch.empty(self.no, 1024, self.h, self.w, dtype=torch.float32, device=self.device)
             if ws is None:
-                ws = _ws(lib.rmnet_bank_read_workspace_bytes(self.no, self.h, self.w), self.device)
+                ws = _ws(lib.rmnet_bank_read_workspace_bytes_for(self.no, self.h, self.w, int(T)), self.device)
             ev = [ctypes.c_void_p(e) if e else None for e in (events or (None, None, None))]
             rc = lib.rmnet_bank_read_f32_at(_ptr(self.blob), self.no, self.capacity, self.h, self.w, int(T), _ptr(_t_dev),
                                             BANK_F16 if self.precision == 'f16' else 0, _ptr(q_key), _ptr(q_val), _ptr(qry_rects), _ptr(out), _ptr(ws),
@@ -297,9 +300,9 @@ class MemoryBank:
 
 class TensorBank:
     """Same interface as ``MemoryBank`` on plain fp32 tensors in the reference's layout
-    ([no,C,Tcap,h,w] + cell rectangles), read with the exact-fp32 kernel: no limit on the number of
-    slots, no limit on the value range, about 4x slower.  The frame loop switches to it for clips with
-    more than 2048 memorised frames and when a ``MemoryBank`` reported out-of-window values."""
+    ([no,C,Tcap,h,w] + cell rectangles), read with the exact-fp32 kernel: no limit on the value range, about
+    4x slower.  The frame loop switches to it when a ``MemoryBank`` reported out-of-window values (beyond 2048
+    memorised frames it falls to the generic kernels, with a warning: the exact fused kernel takes one launch's frames)."""
 
     def __init__(self, no, capacity, h, w, device):
         self.no, self.capacity, self.h, self.w = int(no), int(capacity), int(h), int(w)

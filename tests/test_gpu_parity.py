@@ -392,10 +392,11 @@ def test_rect_mask_vs_oracle(oracle_mod):
 
 
 # ----------------------------------------------------------------------------- the frame loop (P1-P5)
-def _nets(oracle_mod):
+def _nets(oracle_mod, read_precision=None):
+    """The product (frame loop in its DEFAULT arithmetic unless ``read_precision`` is given) and the CPU oracle, same weights."""
     from rmnet_amd import networks
     from rmnet_amd.rmnet import RMNet
-    prod = RMNet(None)
+    prod = RMNet(None) if read_precision is None else RMNet(None, read_precision=read_precision)
     networks.procedural_init_(prod)
     ref = oracle_mod.OracleRMNet()
     ref.load_state_dict(prod.state_dict())
@@ -1321,8 +1322,8 @@ def test_whole_loop_480p_five_objects_and_loader_channel_count(K, n_obj, oracle_
     tools/dbg_loop5.py) -- so the bar there is: fewer than 1e-4 of the values differ by more than 1e-3, none by more than
     2e-2, and the split-fp16 read adds nothing to what the exact read shows."""
     from rmnet_amd.synthetic import synthetic_clip
-    prod, ref = _nets(oracle_mod)
-    prod.fuse_epilogues()
+    prod, ref = _nets(oracle_mod, read_precision='split')       # (the probability statements below are about the fp32-class read;
+    prod.fuse_epilogues()                                       #  the default fp16-operand read: label IoU, at the end)
     H, W, N = 480, 854, 3
     frames, masks, flows, n_objects = synthetic_clip(N, n_obj + 1, H, W, seed=K, size=1.1 if n_obj > 1 else 2.1)
     if K > n_obj + 1:
@@ -1346,6 +1347,11 @@ def test_whole_loop_480p_five_objects_and_loader_channel_count(K, n_obj, oracle_
         assert oracle_mod.iou(lab[:, 1:] == k, lab_cpu[:, 1:] == k) >= 0.999
     if K > n_obj + 1:
         assert float(est[:, 1:, n_obj + 1:].max()) < 1e-6          # channels of objects that do not exist
+    prod.read_precision = 'f16'                                     # the frame loop's default arithmetic: the north star's IoU bar
+    with torch.no_grad():
+        lab16 = prod(frames, masks, flows, n_objects, 1).argmax(2).cpu().numpy()
+    for k in range(1, n_obj + 1):
+        assert oracle_mod.iou(lab16[:, 1:] == k, lab_cpu[:, 1:] == k) >= 0.999
 
 
 def test_exact_fallback_with_tiny_memory_boxes_is_not_nan(oracle_mod):
@@ -1385,27 +1391,55 @@ def test_memory_longer_than_512_frames(oracle_mod):
         np.testing.assert_allclose(got.cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL)
 
 
-def test_bank_at_its_slot_limit(oracle_mod):
-    """The bank's documented limit: 2048 memorised frames are read (both arithmetic modes, a 3x4 grid keeps the oracle fast:
-    the workgroups' LDS tile prefix is full), a bank of 2049 slots is refused with RMNET_E_UNSUPPORTED, not clamped."""
-    from rmnet_amd import _lib, ops
+def test_bank_at_one_launch_limit(oracle_mod):
+    """One launch takes 2048 memorised frames (the workgroups' LDS tile prefix is full): read in both arithmetic modes on a
+    3x4 grid (keeps the oracle fast)."""
+    from rmnet_amd import ops
     assert ops.BANK_MAX_SLOTS == 2048
     rng = np.random.RandomState(2048)
     no, T, h, w = 1, 2048, 3, 4
     mk, mv, qk, qv, mr, qr = _random_case(rng, no, T, h, w, regional=True)
     want, _ = oracle_mod.regional_memory_read(mk, mv, qk, qv, mr, qr)
     bank = ops.MemoryBank(no, T, h, w, dev())
-    lib = _lib.load()
     for t in range(T):
         bank.append(t, cu(mk[:, :, t]), cu(mv[:, :, t]), cu(mr[:, t]))
     np.testing.assert_allclose(bank.read(T, cu(qk), cu(qv), cu(qr)).cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL)
     bank.precision = 'f16'
     _f16_bars(bank.read(T, cu(qk), cu(qv), cu(qr)).cpu().numpy(), want, float(np.abs(mv).max()))
     assert bank.overflow_count() == 0
-    big = torch.zeros(lib.rmnet_bank_bytes(1, 2049, h, w) or 1 << 20, dtype=torch.uint8, device=dev())
-    k4, v4 = cu(mk[:, :, 0]), cu(mv[:, :, 0])
-    rc = lib.rmnet_bank_append_f32(big.data_ptr(), 1, 2049, h, w, 0, k4.data_ptr(), v4.data_ptr(), None, None)
-    assert rc == -4, rc                                            # RMNET_E_UNSUPPORTED
+
+
+@pytest.mark.parametrize('T,regional', [(2049, True), (4100, True), (4100, False)])
+def test_memory_beyond_one_launch_is_read_in_chunks(T, regional, oracle_mod):
+    """models/rmnet.py:416-426 has no bound on the memory: T = 2049 ... 4100 memorised frames through the bank -- chunks of
+    2048 slots, each an ordinary read that also leaves the soft-max state of its queries, merged by bk_chain -- against
+    the oracle, both arithmetic modes; masked query cells, a chunk whose boxes are all empty, and the device-counter entry
+    (refused for such a bank: the chunks are planned on the host)."""
+    from rmnet_amd import _lib, ops
+    rng = np.random.RandomState(T)
+    no, h, w = 2, 3, 4
+    mk, mv, qk, qv, mr, qr = _random_case(rng, no, T, h, w, regional=regional)
+    if regional:
+        mr[1, 2048:] = (1, 0, 1, 0)                    # object 1: nothing memorised inside a box after the first chunk
+        qr[0] = (1, 3, 0, 1)
+        want, _ = oracle_mod.regional_memory_read(mk, mv, qk, qv, mr, qr)
+    else:
+        want, _ = oracle_mod.memory_read(mk, mv, qk, qv)
+    bank = ops.MemoryBank(no, T + 3, h, w, dev())
+    for t in range(T):
+        bank.append(t, cu(mk[:, :, t]), cu(mv[:, :, t]), None if mr is None else cu(mr[:, t]))
+    q_rects = None if qr is None else cu(qr)
+    got = bank.read(T, cu(qk), cu(qv), q_rects).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=MR_ATOL, rtol=MR_RTOL)
+    bank.precision = 'f16'
+    _f16_bars(bank.read(T, cu(qk), cu(qv), q_rects).cpu().numpy(), want, float(np.abs(mv).max()))
+    assert bank.overflow_count() == 0 and bank.timeout_count() == 0
+    bank.precision = 'split'
+    np.testing.assert_allclose(bank.read(2048, cu(qk), cu(qv), q_rects).cpu().numpy()[:, 512:], want[:, 512:], atol=0, rtol=0)   # one launch still works
+    bank.committed = T - 1
+    np.testing.assert_allclose(bank.read_staged(cu(qk), cu(qv), q_rects).cpu().numpy(), want, atol=MR_ATOL, rtol=MR_RTOL)   # host count for long banks
+    with pytest.raises(RuntimeError):
+        bank.read(1, cu(qk), cu(qv), q_rects, _t_dev=bank.n_dev)
 
 
 def test_forward_replays_one_hip_graph_for_the_whole_clip(oracle_mod):
@@ -1761,11 +1795,12 @@ def test_device_counter_out_of_range_is_flagged_and_timeouts_stay_zero(oracle_mo
         bank.assert_synced()
 
 
-def test_default_mode_whole_loop_grows_the_memory_to_five_frames(oracle_mod):
-    """Default (split) arithmetic, 480x854, N = 6 with memorize_every = 1: the memory read by the last frame holds T = 5
-    frames (BASELINE configs[1]'s memory length), fused loop against the CPU path."""
+@pytest.mark.parametrize('precision', ['f16', 'split'])
+def test_whole_loop_grows_the_memory_to_five_frames(precision, oracle_mod):
+    """Both arithmetic modes (f16 = the frame loop's default, split = fp32-class), 480x854, N = 6 with memorize_every = 1:
+    the memory read by the last frame holds T = 5 frames (BASELINE configs[1]'s memory length), fused loop against the CPU path."""
     from rmnet_amd.synthetic import synthetic_clip
-    prod, ref = _nets(oracle_mod)
+    prod, ref = _nets(oracle_mod, read_precision=precision)
     prod.fuse_epilogues()
     frames, masks, flows, n_objects = synthetic_clip(6, 2, 480, 854, seed=11, size=2.1)
     with torch.no_grad():

@@ -4,7 +4,7 @@
 exact fp32 (TensorBank + mr_main), split fp16 (3 MFMA terms) and fp16 operands (1 term) -- on multi-object clips.
 Prints one row per (clip, arithmetic): per-object label IoU vs the CPU path over the whole clip, the worst single-frame IoU,
 and the largest probability difference; plus the same rows against the exact-fp32 GPU run (what the arithmetic alone does).
-    python tools/iou_calib.py [N frames] [threads] [cases]   (cases: comma list of 3o480,5o480,3o720,1o480)"""
+    python tools/iou_calib.py [N frames] [threads] [cases]   [blob size]   (cases: comma list of 3o480,5o480,3o720,1o480)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -16,6 +16,7 @@ dev = torch.device('cuda', 0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 nt = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 want = sys.argv[3].split(',') if len(sys.argv) > 3 else ['3o480', '5o480', '3o720']
+size = float(sys.argv[4]) if len(sys.argv) > 4 else 1.1          # blob radius scale of rmnet_amd.synthetic.synthetic_clip
 CASES = {'1o480': (1, 480, 854, 5, 1), '3o480': (3, 480, 854, 5, 3), '5o480': (5, 480, 854, 2, 4), '3o720': (3, 720, 1280, 3, 5)}
 torch.set_grad_enabled(False)
 torch.set_num_threads(nt)
@@ -42,11 +43,11 @@ prod = networks.procedural_init_(RMNet(None)).to(dev).eval()
 prod.fuse_epilogues()
 for name in want:
     n_obj, H, W, every, seed = CASES[name]
-    frames, masks, flows, n_objects = synthetic_clip(N, n_obj + 1, H, W, seed=seed, size=1.1)
+    frames, masks, flows, n_objects = synthetic_clip(N, n_obj + 1, H, W, seed=seed, size=size)
     t0 = time.time()
     ref = cpu(frames, masks, flows, n_objects, every)
-    print('%s: %d objects %dx%d, %d frames, memorize_every %d; CPU path %.0f s at %d threads; object cover of the last frame: %s'
-          % (name, n_obj, H, W, N, every, time.time() - t0, nt,
+    print('%s (blob size %.1f): %d objects %dx%d, %d frames, memorize_every %d; CPU path %.0f s at %d threads; object cover of the last frame: %s'
+          % (name, size, n_obj, H, W, N, every, time.time() - t0, nt,
              ' '.join('%.3f' % float((ref[0, -1].argmax(0) == k).float().mean()) for k in range(1, n_obj + 1))), flush=True)
     runs = {}
     runs['exact'] = prod(frames, masks, flows, n_objects, every, _exact=True).cpu()

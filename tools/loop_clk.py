@@ -57,6 +57,7 @@ if raw[:, 1].max() > 0:
     def st(col, sel):
         v = us[sel, col]
         return '%.1f [%.1f..%.1f]' % (np.median(v), v.min(), v.max())
+    print('plan inputs in LDS %s' % st(7, comp))
     print('compute WGs (%d): plan done %s; first walk starts %s; last walk over %s; compute part over %s; left %s'
           % (comp.sum(), st(4, comp), st(5, comp), st(6, comp), st(1, comp), st(3, comp)))
     aside = ~comp & (us[:, 3] > 0)
