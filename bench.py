@@ -366,9 +366,10 @@ def main():
                     help='independent clips batched on every GPU (one 480p clip cannot fill 256 CUs; measured '
                          'on MI355X: 164 / 194 / 227 / 248 / 247 frames/s at 1 / 2 / 4 / 8 / 10 clips)')
     ap.add_argument('--graph', action='store_true', help='replay the frame step as one captured HIP graph')
-    ap.add_argument('--read-precision', choices=('split', 'f16'), default='f16',
-                    help="arithmetic of the bank read in the timed region: 'split' = fp16 hi/lo pairs, three MFMA terms, fp32-class "
-                         "(default); 'f16' = fp16 operands, one term, ~2^-11 relative (opt-in mode, include/rmnet_hip.h).  The other "
+    ap.add_argument('--read-precision', choices=('auto', 'split', 'f16'), default='auto',
+                    help="arithmetic of the bank read in the timed region: 'auto' (default, = RMNet's default) picks 'f16' for clips with one "
+                         "object -- this workload -- and 'split' for clips with several (profiles/r04_iou_calibration.md); 'split' = fp16 hi/lo "
+                         "pairs, three MFMA terms, fp32-class; 'f16' = fp16 operands, one term, ~2^-11 relative.  The other "
                          "mode's kernel is timed on the same launches after the timed region and reported under roofline.modes")
     ap.add_argument('--dist-backend', default=None, help="override the process-group backend ('gloo' lets several "
                     "ranks share one GPU when testing the N>1 path on a 1-GPU box)")
@@ -392,6 +393,8 @@ def main():
 
     _phase('imports done')
     net = networks.procedural_init_(RMNet(None, read_precision=args.read_precision)).to(dev).eval()
+    requested_precision = args.read_precision
+    args.read_precision = net.resolve_read_precision([K_CH - 1] * max(1, args.clips_per_gpu))   # what 'auto' means for one object per clip
     tfn = networks.procedural_init_(TinyFlowNet(None)).to(dev).eval()
     if args.fold_bn:
         net.fuse_for_inference()
@@ -667,7 +670,7 @@ def main():
         torch.cuda.synchronize()
         dt_free_g = time.perf_counter() - t1
         saved_prec = net.read_precision
-        net.read_precision = 'f16' if saved_prec == 'split' else 'split'
+        net.read_precision = 'f16' if args.read_precision == 'split' else 'split'
         net(ff[:, :6], fm[:, :6], tfn(ff[:, :6]), fn_obj[:, :6], 5)          # warm-up
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -719,7 +722,8 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': ('f32 (convs fp32; memory read = split-fp16 MFMA hi*hi+hi*lo+lo*hi with fp32 accumulate, fp32-class accuracy)'
                       if args.read_precision == 'split' else
-                      'f32 convs; memory read = fp16 operands (K, V, q, P rounded to 11 bits), fp32 accumulate: the opt-in RMNET_BANK_F16 mode'),
+                      'f32 convs; memory read = fp16 operands (K, V, q, P rounded to 11 bits), fp32 accumulate (RMNET_BANK_F16): the frame '
+                      'loop\'s default for clips with one object -- mask IoU vs the CPU path 1.0000 on this workload (profiles/r04_iou_calibration.md)'),
             'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: 480x854 synthetic clips, 1 object each (K=2), memory pinned '
                                    'at T=5, TinyFlowNet + memorize + regional read + decoder per frame; '
@@ -736,7 +740,7 @@ def main():
                          'kernel': 'bk_main<%d> = the whole regional memory read in ONE launch (%s MFMA read of the bank, merge of the '
                                    'partial results by the last workgroup of every query tile, masked cells, q_val half of the cat)'
                                    % (n_terms, 'split-fp16 (3-term)' if n_terms == 3 else 'fp16-operand (1-term)'),
-                         'read_precision': args.read_precision,
+                         'read_precision': args.read_precision, 'read_precision_requested': requested_precision,
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                          'definition': 'SURVEY.md 8d / BASELINE.json: algorithmic bytes per launch (%d B = %d object-frames x 31,518,720 B) / '
                                        'mean kernel duration, against 8 TB/s HBM' % (abytes, B * (K_CH - 1)),
@@ -766,10 +770,11 @@ def main():
             line['roofline']['modes'] = {
                 args.read_precision: this, other_mode: other,
                 'note': "the same launches (same bank, same boxes) in both arithmetic modes of the kernel, whole read, HIP events on the "
-                        "launch stream; the top-level figures are the timed region's mode ('%s').  split = default, fp32-class (error 1e-7); "
-                        "f16 = opt-in RMNET_BANK_F16: fp16 operands, fp32 accumulate, read-out error ~2^-11 of the values (3e-4 worst, 5e-6 "
-                        "typical), whole-clip mask IoU vs the CPU path 1.0000 for this workload, >= 0.9985 for 3-5 objects on random-init "
-                        "weights (tests/test_gpu_parity.py, extras.free_running.f16_vs_split)" % args.read_precision}
+                        "launch stream; the top-level figures are the timed region's mode ('%s').  split = fp32-class (error 1e-7), the loop's default "
+                        "for clips with several objects; f16 = RMNET_BANK_F16: fp16 operands, fp32 accumulate, read-out error ~2^-11 of the values "
+                        "(3e-4 worst, 5e-6 typical), the loop's default for one object per clip (this workload): whole-clip mask IoU vs the CPU path "
+                        "1.0000; with 3 / 5 objects per clip 0.9991-0.9995 / 0.9986-0.9992 on random-init weights, exact fp32 on the GPU >= 0.9997 "
+                        "(profiles/r04_iou_calibration.md, tests/test_gpu_parity.py)" % args.read_precision}
         if extras is not None and extras.get('single_stream_fps'):
             line['config']['workload'] += ' -- value = %d clips batched per GPU; ONE 480p stream alone: %.1f frames/s' % (B, extras['single_stream_fps'])
         else:

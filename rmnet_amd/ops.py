@@ -179,6 +179,14 @@ def _precision(p):
     return p
 
 
+def _loop_precision(p):
+    """Arithmetic of the frame loop's bank read: 'auto' (default), 'f16' or 'split'.  'auto' picks per clip batch:
+    'f16' when every clip has ONE object, 'split' otherwise -- see RMNet.__init__ and profiles/r04_iou_calibration.md."""
+    if p not in ('auto', 'split', 'f16'):
+        raise ValueError("read_precision must be 'auto', 'split' or 'f16'")
+    return p
+
+
 class MemoryBank:
     """Device-resident regional memory of one clip: ``no`` objects x ``capacity`` frame slots on an
     h x w feature grid (csrc/bank.hip).  ``append`` writes a slot from the un-masked KeyValue outputs

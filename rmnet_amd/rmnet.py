@@ -64,16 +64,18 @@ class RMNet(nn.Module):
     ``torch.no_grad()`` and refuse to run in training mode (the reference's training path -- losses,
     DataParallel, models/rmnet.py's ``self.training`` branches -- is out of scope)."""
 
-    def __init__(self, cfg=None, read_precision='f16'):
+    def __init__(self, cfg=None, read_precision='auto'):
         super().__init__()
         self.cfg = cfg
         # arithmetic of the bank read in the frame loop:
-        #   'f16' (default since round 4) = fp16 operands, fp32 accumulate, ~2^-11 relative per read-out, 1.5-2x as fast.  The
-        #          task's bar is mask IoU within 1e-3 of the CPU path; calibrated against that path on 20-frame 3- and 5-object
-        #          480p clips and a 720p 3-object clip (profiles/r04_iou_calibration.md, tests/test_gpu_parity.py): every object
-        #          >= 0.999 (exact fp32 on the GPU itself: 0.99987-0.99998 on the same clips);
-        #   'split' = fp16 hi/lo pairs, three MFMA terms, fp32-class accuracy (1e-7) -- what rounds 1-3 shipped as the default.
-        self.read_precision = ops._precision(read_precision)
+        #   'f16'   = fp16 operands, fp32 accumulate, ~2^-11 relative per read-out, 1.5-2x as fast;
+        #   'split' = fp16 hi/lo pairs, three MFMA terms, fp32-class accuracy (1e-7) -- what rounds 1-3 ran everywhere;
+        #   'auto' (default since round 4) = 'f16' for clips with ONE object, 'split' for clips with several.
+        # The task's bar is mask IoU within 1e-3 of the CPU path.  Calibrated against that path (profiles/r04_iou_calibration.md,
+        # tests/test_gpu_parity.py) on procedural random weights: with one object per clip the fp16-operand loop gives IoU 1.0000
+        # (20-frame and 67-frame clips); with three objects 0.9991-0.9995; with five 0.9986-0.9992, i.e. not reliably inside the
+        # bar (the exact-fp32 GPU loop itself: >= 0.9997) -- the soft aggregation over several objects amplifies the read's 2^-11.
+        self.read_precision = ops._loop_precision(read_precision)
         self.encoder_memory = EncoderMemory()
         self.encoder_query = EncoderQuery()
         self.kv_memory = KeyValue(1024, keydim=128, valdim=512)
@@ -309,7 +311,13 @@ class RMNet(nn.Module):
         soft-max state), or -- ``exact`` -- plain fp32 tensors read by the exact-fp32 kernel (``TensorBank``)."""
         if exact:
             return ops.TensorBank(len(ctx.flat), capacity, ctx.h, ctx.w, ctx.device)
-        return ops.MemoryBank(len(ctx.flat), capacity, ctx.h, ctx.w, ctx.device, precision=self.read_precision)
+        return ops.MemoryBank(len(ctx.flat), capacity, ctx.h, ctx.w, ctx.device, precision=self.resolve_read_precision(ctx.n_max))
+
+    def resolve_read_precision(self, n_objects):
+        """The arithmetic ``read_precision`` stands for on clips with ``n_objects`` objects each ('auto': see __init__)."""
+        if self.read_precision != 'auto':
+            return self.read_precision
+        return 'f16' if all(int(n) <= 1 for n in n_objects) else 'split'
 
     @torch.no_grad()
     def frame_step(self, ctx, bank, prev_frame, prev_mask, cur_frame, cur_flow, commit):

@@ -94,7 +94,10 @@ def test_flag_constants_of_the_python_mirror_match_the_header():
         ops._precision('bf16')
     with pytest.raises(ValueError):
         RMNet(None, read_precision='fp8')
-    assert RMNet(None).read_precision == 'f16' and MemoryReader().precision == 'split'      # frame loop: the calibrated fp16-operand read; the stand-alone reader: fp32-class unless asked
+    net = RMNet(None)
+    assert net.read_precision == 'auto' and MemoryReader().precision == 'split'      # the stand-alone reader: fp32-class unless asked
+    assert net.resolve_read_precision([1, 1, 1]) == 'f16' and net.resolve_read_precision([1, 3]) == 'split'   # calibrated per-clip choice
+    assert RMNet(None, read_precision='f16').resolve_read_precision([5]) == 'f16'
     lib = _lib.load()
     # the fp16 switch is the only flag rmnet_bank_read_f32_at knows: anything else is refused before any launch
     assert lib.rmnet_bank_read_f32_at(None, 1, 1, 4, 4, 1, None, 8, None, None, None, None, None, 0, None, None, None, None) == -1

@@ -1640,27 +1640,60 @@ def test_f16_mode_whole_clip_meets_the_iou_bar(oracle_mod):
         assert oracle_mod.iou(lab[:, 1:] == 1, lab_cpu[:, 1:] == 1) >= 0.999
 
 
-def test_f16_mode_multi_object_clips_against_the_default_mode(oracle_mod):
-    """Several objects, longer clips: the fp16-operand loop against the default (fp32-class) loop on the GPU, 20 frames.
-    With these procedural random weights the network amplifies a 1e-6 perturbation to a few 1e-3 of probability in a
-    handful of pixels (tools/dbg_loop5.py), so this is a statement about a chaotic map, not about trained weights:
-    per-object clip IoU >= 0.998 (measured 0.9985-0.99996; the default mode against the exact-fp32 read: >= 0.9998).
-    The reference task's bar of 1e-3 is met for one object (test above) and for three (0.9992); for five objects on
-    these weights it is not (0.9985), which is why the mode is opt-in."""
-    from rmnet_amd import networks
-    from rmnet_amd.rmnet import RMNet
+_CALIB_CASES = {   # objects, H, W, memorize_every, seed, blob size, frames
+    '1obj-480p': (1, 480, 854, 5, 1, 2.1, 20),
+    '3obj-480p': (3, 480, 854, 5, 3, 1.1, 20),
+    '5obj-480p': (5, 480, 854, 2, 4, 1.6, 20),     # (the configuration on which the fp16-operand loop misses the bar: 0.9989)
+    '3obj-720p': (3, 720, 1280, 3, 5, 1.1, 12),
+}
+
+
+@pytest.mark.parametrize('case', sorted(_CALIB_CASES))
+def test_iou_bar_against_the_cpu_path_on_long_clips(case, oracle_mod):
+    """The north star's bar -- mask IoU within 1e-3 of the CPU path -- measured against THAT path (OracleRMNet on the host
+    cores) on 20-frame clips with 1 / 3 / 5 objects at 480x854 and a 12-frame 720p clip, for the GPU loop in its default
+    configuration ('auto': fp16-operand read for one object per clip, split-fp16 for several), with the exact-fp32 read and
+    with the fp16-operand read forced.  Bars: default and exact >= 0.999 per object on every clip; fp16 forced >= 0.999 with
+    one object (probabilities within 1e-3 as well) and >= 0.998 otherwise (measured 0.9986-0.9995 on these procedural random
+    weights: that margin is why 'auto' does not use it there; profiles/r04_iou_calibration.md has the table of the 30-frame
+    and other-size runs, tools/iou_calib.py makes it)."""
     from rmnet_amd.synthetic import synthetic_clip
-    prod = networks.procedural_init_(RMNet(None)).to(dev()).eval()
+    n_obj, H, W, every, seed, size, N = _CALIB_CASES[case]
+    prod, ref = _nets(oracle_mod)
     prod.fuse_epilogues()
-    for n_obj, every, seed, bar in [(3, 5, 3, 0.999), (5, 2, 4, 0.998)]:
-        frames, masks, flows, n_objects = synthetic_clip(20, n_obj + 1, 480, 854, seed=seed, size=1.1)
+    assert prod.read_precision == 'auto'
+    frames, masks, flows, n_objects = synthetic_clip(N, n_obj + 1, H, W, seed=seed, size=size)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(32, threads))
+    oracle_mod.set_num_threads(min(32, threads))
+    try:
         with torch.no_grad():
-            prod.read_precision = 'split'
-            a = prod(frames, masks, flows, n_objects, every).argmax(2).cpu().numpy()
-            prod.read_precision = 'f16'
-            b = prod(frames, masks, flows, n_objects, every).argmax(2).cpu().numpy()
-        for k in range(1, n_obj + 1):
-            assert oracle_mod.iou(a[:, 1:] == k, b[:, 1:] == k) >= bar, (n_obj, k)
+            est_cpu = ref(frames, masks, flows, n_objects, every)
+    finally:
+        torch.set_num_threads(threads)
+        oracle_mod.set_num_threads(threads)
+    lab_cpu = est_cpu.argmax(2).numpy()
+
+    def run(precision, exact=False):
+        prod.read_precision = precision
+        with torch.no_grad():
+            est = prod(frames, masks, flows, n_objects, every, _exact=exact).cpu()
+        lab = est.argmax(2).numpy()
+        return min(oracle_mod.iou(lab[:, 1:] == k, lab_cpu[:, 1:] == k) for k in range(1, n_obj + 1)), est
+    iou_auto, _ = run('auto')
+    iou_exact, _ = run('auto', exact=True)
+    iou_f16, est_f16 = run('f16')
+    prod.read_precision = 'auto'
+    assert prod.resolve_read_precision([n_obj]) == ('f16' if n_obj == 1 else 'split')
+    assert iou_exact >= 0.999 and iou_auto >= 0.999, (case, iou_exact, iou_auto, iou_f16)
+    if n_obj == 1:
+        assert iou_f16 >= 0.999 and float((est_f16 - est_cpu).abs().max()) < 1e-3, (case, iou_f16)
+    else:
+        assert iou_f16 >= 0.998, (case, iou_f16)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(out):
+        with open(os.path.join(out, 'iou_bar_test_table.txt'), 'a') as fh:
+            fh.write('%s: default(auto) %.5f exact %.5f f16 %.5f\n' % (case, iou_auto, iou_exact, iou_f16))
 
 
 def test_f16_mode_through_strides_partial_reads_and_graph_replay(oracle_mod):
