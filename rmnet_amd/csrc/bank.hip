@@ -1363,7 +1363,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     o_nqt[tid] = (Mq + kQT - 1) / kQT;
   }
   if (fastplan) {
-    const int tiles = wave_sum((my_ar + kJT - 1) / kJT), cells = wave_sum(my_ar);
+    const int tiles = wave_sum_fast((my_ar + kJT - 1) / kJT), cells = wave_sum_fast(my_ar);
     if (lane0 == 0 && wave < ng) { o_njt[wave] = tiles; o_m[wave] = cells; }
   } else {
     __syncthreads();
@@ -1380,7 +1380,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
 #endif
   if (tid < RMNET_WAVE) {   // one wave, lane = object
     const int nqt = tid < ng ? o_nqt[tid] : 0, njt = tid < ng ? o_njt[tid] : 0;
-    const int W = wave_sum(nqt * njt), njt_max = wave_max(njt);
+    const int W = wave_sum_fast(nqt * njt), njt_max = wave_max_fast(njt);
     // workgroups set aside for the static part: what it takes to stream it in about the time the others compute
     // (the finishers drain whatever is left, so a wrong guess costs little either way)
     int target = a.target;
@@ -1391,21 +1391,43 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
       aside = min(aside, a.target / 4);
       target = a.target - aside;
     }
-    // smallest chunk length whose chunks fit `target` workgroups (sum_o nch(o) shrinks as C grows)
+    // smallest chunk length whose chunks fit `target` workgroups (sum_o nch(o) shrinks as C grows).  The candidates are the
+    // sequence C, next(C), next(next(C)), ...; FOUR of them are priced per round (independent divisions and reductions
+    // overlap): this search sits on the critical path of every workgroup, and one candidate at a time with shuffle
+    // reductions cost 0.45 us per step, 3 us at the bench launch (r04 time line).
     constexpr int kSC = kTerms == 1 ? kSegCostF16 : kSegCost;
     constexpr int kCq = kTerms == 1 ? 2 : 1;              // (fp16 mode: a step is two tiles, an odd chunk wastes half of one)
+    auto next_c = [](int c) { return c + (1 + (c >> 5) + kCq - 1) / kCq * kCq; };
+    // chunks of this lane's object at chunk length c = bank_chunks(nqt, njt, c, kSC).nch with the two integer divisions done in
+    // fp32 (all operands < 2^22: the quotient is off by at most one, fixed up) -- ~15 instructions instead of ~80
+    auto fdiv = [](int x, int c, float rc) {
+      int q = (int)((float)x * rc);
+      const int r = x - q * c;
+      q += (r >= c) - (r < 0);
+      return q;
+    };
+    auto nch_at = [&](int c) {
+      const float rc = __builtin_amdgcn_rcpf((float)c);
+      const int nfull = fdiv(njt, c, rc), R = njt - nfull * c;
+      const int nrem = R > 0 && nqt > 0 ? fdiv(nqt * (R + kSC) - kSC + c - 1, c, rc) : 0;
+      return nqt * nfull + nrem;
+    };
     int C0 = max((W + target - 1) / target, bank_chunk_min(njt_max));
     C0 = (C0 + kCq - 1) / kCq * kCq;
-    for (int it = 0; it < 1024 && wave_sum(bank_chunks(nqt, njt, C0, kSC).nch) > target; ++it) C0 += (1 + (C0 >> 5) + kCq - 1) / kCq * kCq;
-    const bool own = wave_sum(bank_chunks(nqt, njt, C0, kSC, true).nch) <= target;   // short objects as blocks of their own (common.h)
-    const BankChunks bc0 = bank_chunks(nqt, njt, C0, kSC, own);
-    int nch = bc0.nch, nsl = bc0.nch + (bc0.R > 0 ? nqt : 0);   // chunks; slots (a remainder chunk can add one per query tile)
-    const int my_ch = nch, my_sl = nsl;
-#pragma unroll
-    for (int d = 1; d < RMNET_WAVE; d <<= 1) {
-      const int u1 = __shfl_up(nch, d), u2 = __shfl_up(nsl, d);
-      if (tid >= d) { nch += u1; nsl += u2; }
+    for (int it = 0; it < 256; ++it) {
+      const int c1 = next_c(C0), c2 = next_c(c1), c3 = next_c(c2);
+      const int n0 = wave_sum_fast(nch_at(C0)), n1 = wave_sum_fast(nch_at(c1));
+      const int n2 = wave_sum_fast(nch_at(c2)), n3 = wave_sum_fast(nch_at(c3));
+      if (n0 <= target) break;
+      if (n1 <= target) { C0 = c1; break; }
+      if (n2 <= target) { C0 = c2; break; }
+      if (n3 <= target) { C0 = c3; break; }
+      C0 = next_c(c3);
     }
+    const bool own = wave_sum_fast(bank_chunks(nqt, njt, C0, kSC, true).nch) <= target;   // short objects as blocks of their own (common.h)
+    const BankChunks bc0 = bank_chunks(nqt, njt, C0, kSC, own);
+    const int my_ch = bc0.nch, my_sl = bc0.nch + (bc0.R > 0 ? nqt : 0);   // chunks; slots (a remainder chunk can add one per query tile)
+    const int nch = wave_scan_incl_fast(my_ch), nsl = wave_scan_incl_fast(my_sl);
     if (tid < ng) { o_cb[tid] = nch - my_ch; o_sb[tid] = nsl - my_sl; }
     if (tid == RMNET_WAVE - 1) { plan_n = nch; plan_c = bc0.C; plan_own = own ? 1 : 0; }
   }
@@ -1432,29 +1454,32 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     const int q8 = nchunks >> 3, r8 = nchunks & 7, x = blockIdx.x & 7;   // XCD-contiguous logical ids
     c = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (blockIdx.x >> 3);
   }
-  int og = 0;
-  for (int i = 1; i < ng; ++i)
-    if (sld(o_cb[i]) <= c) og = i;          // (objects without chunks share the next one's base: the later one wins)
-  const int nqt = sld(o_nqt[og]), njt = sld(o_njt[og]);
+  // object of chunk c = the last one whose chunk base is <= c (objects without chunks share the next one's base: the later one
+  // wins); lane i looks at object i, and the nine plan values of the object travel LDS -> registers -> SGPRs in ONE round trip
+  // (a serial search + a dozen dependent LDS reads cost ~1 us here)
+  const int li = tid & 63;
+  const bool lv = li < ng;
+  const int v_cb = lv ? o_cb[li] : 0x7fffffff, v_nqt = lv ? o_nqt[li] : 0, v_njt = lv ? o_njt[li] : 0, v_sb = lv ? o_sb[li] : 0;
+  const int v_m = lv ? o_m[li] : 0, v_r0 = lv ? o_rect[li][0] : 0, v_r1 = lv ? o_rect[li][1] : 0, v_r2 = lv ? o_rect[li][2] : 0;
+  const int v_r3 = lv ? o_rect[li][3] : 0;
+  const unsigned long long le = __ballot(v_cb <= c);
+  const int og = le ? 63 - __builtin_clzll(le) : 0;
+  auto pick = [&](int v) { return __builtin_amdgcn_readlane(v, og); };
+  const int nqt = pick(v_nqt), njt = pick(v_njt);
   const BankChunks bc = bank_chunks(nqt, njt, C, kTerms == 1 ? kSegCostF16 : kSegCost, sld(plan_own) != 0);
-  const int cl = c - sld(o_cb[og]);         // chunk inside the object
+  const int cl = c - pick(v_cb);            // chunk inside the object
   const int lane = tid & 63;
   Walk wk;
   wk.o = a.obj0 + og;
-  wk.qr = Rect{sld(o_rect[og][0]), sld(o_rect[og][1]), sld(o_rect[og][2]), sld(o_rect[og][3])};
+  wk.qr = Rect{pick(v_r0), pick(v_r1), pick(v_r2), pick(v_r3)};
   wk.Mq = wk.qr.area();
-  const int slot_obj = a.slot0 + sld(o_sb[og]);
-  const float n_out = (float)(T_ * hw - sld(o_m[og]));      // masked memory cells: S = 0, V = 0 (file header)
+  const int slot_obj = a.slot0 + pick(v_sb);
+  const float n_out = (float)(T_ * hw - pick(v_m));         // masked memory cells: S = 0, V = 0 (file header)
 
   // ---- this object's tile prefix over the T memorised frames
   if (fastplan) {
     if (wave == og) {   // the wave that holds this object's areas
-      int sc = (my_ar + kJT - 1) / kJT;
-#pragma unroll
-      for (int d = 1; d < RMNET_WAVE; d <<= 1) {
-        const int up = __shfl_up(sc, d);
-        if (lane0 >= d) sc += up;
-      }
+      const int sc = wave_scan_incl_fast((my_ar + kJT - 1) / kJT);
       if (lane0 < T_) { tpre[lane0 + 1] = sc; tarea[lane0] = my_ar; }
       if (lane0 == 0) tpre[0] = 0;
     }
@@ -1463,14 +1488,9 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     for (int base = 0; base < T_; base += RMNET_WAVE) {
       const int t = base + tid;
       const int ar = t < T_ ? b.area[(size_t)wk.o * b.Tcap + t] : 0;
-      int sc = (ar + kJT - 1) / kJT;
-#pragma unroll
-      for (int d = 1; d < RMNET_WAVE; d <<= 1) {
-        const int up = __shfl_up(sc, d);
-        if (tid >= d) sc += up;
-      }
+      const int sc = wave_scan_incl_fast((ar + kJT - 1) / kJT);
       if (t < T_) { tpre[t + 1] = carry + sc; tarea[t] = ar; }
-      carry += __shfl(sc, RMNET_WAVE - 1);
+      carry += __builtin_amdgcn_readlane(sc, RMNET_WAVE - 1);
     }
     if (tid == 0) tpre[0] = 0;
   }
@@ -1479,10 +1499,15 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   // One segment = the tile walk (producer / consumer roles) + its epilogue.  `sself` = this segment's position in
   // the pair's slot list.
   auto run_segment = [&](int sself) {
-    int lo = 0, hi = T_;   // frame of the first tile
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (sld(tpre[mid]) <= wk.jt0) lo = mid; else hi = mid;
+    int lo = 0, hi = T_;   // frame of the first tile: the last t with tpre[t] <= jt0 (tpre is non-decreasing, tpre[0] = 0)
+    if (T_ <= RMNET_WAVE) {
+      const int lt = tid & 63;
+      lo = __popcll(__ballot(lt < T_ && tpre[lt] <= wk.jt0)) - 1;
+    } else {
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (sld(tpre[mid]) <= wk.jt0) lo = mid; else hi = mid;
+      }
     }
     wk.t = lo;
     int ln = lane;

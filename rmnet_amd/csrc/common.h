@@ -60,6 +60,43 @@ __device__ inline int wave_max(int v) {
   return v;
 }
 
+#if defined(__HIPCC__)
+// Wave-wide integer reductions / scan on the VALU's data-parallel primitives (DPP row operations inside a row of 16 lanes, then
+// v_permlane16_swap / v_permlane32_swap across the four rows) instead of __shfl_*: hipcc lowers a shuffle to ds_bpermute, i.e.
+// one LDS crossbar round trip (~100+ cycles) per step, and the launch plan of bk_main runs a dozen of them back to back on the
+// critical path of every workgroup.
+#define RMNET_DPP(old, src, ctrl, rmask, bmask, bc) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rmask), (bmask), (bc))
+__device__ inline int wave_sum_fast(int v) {          // every lane gets the sum over the 64 lanes
+  v += RMNET_DPP(0, v, 0xB1, 0xf, 0xf, false);        // quad_perm [1,0,3,2]
+  v += RMNET_DPP(0, v, 0x4E, 0xf, 0xf, false);        // quad_perm [2,3,0,1]: every lane = its quad's sum
+  v += RMNET_DPP(0, v, 0x141, 0xf, 0xf, false);       // row_half_mirror: + the other quad of the half row
+  v += RMNET_DPP(0, v, 0x140, 0xf, 0xf, false);       // row_mirror: + the other half of the row
+  auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+  v = (int)r[0] + (int)r[1];
+  r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+  return (int)r[0] + (int)r[1];
+}
+__device__ inline int wave_max_fast(int v) {
+  v = max(v, RMNET_DPP(v, v, 0xB1, 0xf, 0xf, false));
+  v = max(v, RMNET_DPP(v, v, 0x4E, 0xf, 0xf, false));
+  v = max(v, RMNET_DPP(v, v, 0x141, 0xf, 0xf, false));
+  v = max(v, RMNET_DPP(v, v, 0x140, 0xf, 0xf, false));
+  auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+  v = max((int)r[0], (int)r[1]);
+  r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+  return max((int)r[0], (int)r[1]);
+}
+__device__ inline int wave_scan_incl_fast(int v) {    // lane l gets v[0] + ... + v[l]
+  v += RMNET_DPP(0, v, 0x111, 0xf, 0xf, true);        // row_shr:1 (lanes shifted in from outside the row read 0)
+  v += RMNET_DPP(0, v, 0x112, 0xf, 0xf, true);        // row_shr:2
+  v += RMNET_DPP(0, v, 0x114, 0xf, 0xf, true);        // row_shr:4
+  v += RMNET_DPP(0, v, 0x118, 0xf, 0xf, true);        // row_shr:8  -> inclusive scan inside every row of 16
+  v += RMNET_DPP(0, v, 0x142, 0xa, 0xf, false);       // row_bcast15 into rows 1 and 3: + the total of the row before
+  v += RMNET_DPP(0, v, 0x143, 0xc, 0xf, false);       // row_bcast31 into rows 2 and 3: + the total of the first 32 lanes
+  return v;
+}
+#endif
+
 // Launchers (one per .hip file); each returns RMNET_OK or a negative code.
 int launch_region_map_warped(const float* mask, const float* flow, int B, int K, int H, int W,
                              float thr, int n_pts, int loose, float* att, int32_t* bboxes,
