@@ -316,7 +316,7 @@ constexpr int kLdsBytes = 8 * kKbuf                        // K hi/lo x 4 ring s
                           + 3 * kQT * 4                    // alpha [buf][16 queries][4 query tiles]
                           + (kMaxT + 4) * 4                // tile prefix
                           + kMaxT * 4                      // cells per frame
-                          + 4 * 256;                       // landing patches of the producers' L2 prefetch (fp16 mode)
+                          + 12 * 256;                      // landing patches of the L2 prefetch, one per wave (fp16 mode)
 static_assert(kLdsBytes + 4096 <= kLdsBytesPerCU, "bk_main's LDS (tile rings + the prefix arrays of kMaxT frames + plan scratch) must fit one CU");
 constexpr int kProducers = 4;                              // waves 0-3
 constexpr int kConsumers = 8;                              // waves 4-11
@@ -355,12 +355,6 @@ constexpr int kRThreads = 64 * (kProducers + kConsumers);  // 768 = 12 waves = 3
 #endif
 #ifndef BK_PF
 #define BK_PF 7        // fp16 mode: L2 prefetch distance in steps (0 = off), see producer_loop_f16
-#endif
-#ifndef BK_PF_NLD
-#define BK_PF_NLD 1    // fp16 mode: prefetch loads per producer wave and step (256 lines each)
-#endif
-#ifndef BK_PF_DMA
-#define BK_PF_DMA 1    // fp16 mode: prefetch by LDS-DMA into a junk patch (no destination register, never waited for) instead of counted loads
 #endif
 #ifndef BK_PF_REM
 #define BK_PF_REM 0    // fp16 mode: remainder chunks prefetch all of their lines themselves (0 = they do not prefetch)
@@ -425,6 +419,23 @@ struct Cursor {
 #define BK_STAMP() do {} while (0)
 #endif
 
+// A q_key element of a query INSIDE the box whose scaled value leaves fp16's window (|x| * qscale >= 65504, i.e. |q_key| beyond
+// ~8e3), or a NaN / Inf, cannot be represented in the query fragments: it is counted in the bank's overflow word, like an
+// out-of-window memory element, and the caller re-reads exactly (rmnet_hip.h).  The test runs on the fp16 fragments themselves
+// (magnitude bits >= 65504: the split mode saturates there, the fp16 mode converts to Inf; NaN patterns are larger still) and
+// AFTER the tile walk: in the producers' prologue the same ~100 instructions cost the workgroup 2.5 us of its critical path
+// (r04, bench loop), after the walk they are free.
+__device__ inline void query_range_check(const BankView& b, const half8 (&qh)[4], bool qvalid) {
+  unsigned um = 0u;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const u32x4 d = __builtin_bit_cast(u32x4, qh[ks]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) um = max(um, max(d[i] & 0x7fffu, (d[i] >> 16) & 0x7fffu));
+  }
+  if (qvalid && um >= 0x7bffu) atomicAdd(b.ovf, 1);
+}
+
 // ---------------------------------------------------------------- producers: S and soft-max
 // Barrier protocol (identical count in consumer_loop): A, B, then one per tile.
 //   pre A        consumers: K(0..3) -> ring slots 0..3
@@ -463,18 +474,15 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
     // MFMAs in the log2 domain (times 2^12, see kSraw) and the soft-max is one fma + v_exp_f32 (= 2^x)
     // per element.
     const float keep = qvalid ? a.qscale : 0.0f;
-    bool qover = false;                 // a query element outside fp16's window after scaling (|q_key| > ~8e3), NaN or Inf
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float x = qb[(size_t)(32 * ks + 8 * g + e) * b.hw] * keep;
         _Float16 hi, lo;
-        split_f16(x, hi, lo);
-        qover |= !(fabsf(x) <= 65504.0f);
+        split_f16(x, hi, lo);              // (saturates; an element outside the window is COUNTED by a consumer wave: query_range_check)
         qh[ks][e] = hi; ql[ks][e] = lo;
       }
-    if (qover && qvalid) atomicAdd(b.ovf, 1);   // counted like a memorised element: the caller re-reads exactly (rmnet_hip.h)
   }
   float mref = -INFINITY, lsum = 0.0f;
 
@@ -666,6 +674,7 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
   }
   m_out = mref * kSraw;                                // log2 domain; the segment's epilogue takes it from here
   l_out = lsum;
+  query_range_check(b, qh, wk.qt * kQT + wave * 16 + l15 < wk.Mq);
   BK_STAMP();
 }
 
@@ -782,6 +791,59 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
 
 }
 
+// ---- L2 prefetch of the fp16-operand walk.  Inside the frame loop nothing of the bank is in a cache when the read starts (the
+// convolutions between two reads stream hundreds of MB), a V fragment load is issued ONE step (~1.3 us) before its use and an
+// HBM miss under load takes longer than that: the tile walk then runs at memory latency, not at the matrix pipe's pace (measured
+// in the loop: 1.77 us per step against 1.30 with a warm cache).  The nqt workgroups of a column block walk the same K / V tiles
+// in lockstep on one XCD, i.e. behind one L2: each of them touches 1/nqt of the 128-byte lines of the step BK_PF steps ahead
+// (one dword per line) so that the demand loads of all of them hit the L2.  The touch is an LDS-DMA load into a 256-byte junk
+// patch of the issuing wave: no destination register, nothing ever waits for it (hipcc does not see the load: its own counted
+// waits only get more conservative; __syncthreads() stays a bare barrier).  In the loop the producers issue it (one wave
+// instruction per step for the usual 12 query tiles); the first BK_PF - 1 steps are touched by the CONSUMERS while they wait for
+// the producers' first soft-max -- in the producers' own prologue those address computations sat on the critical path of the
+// whole workgroup.
+struct L2Prefetch {
+  static constexpr int kLinesK = kJT * kDe * 2 / 128, kLinesV = kDo * kJT * 2 / 128, kLinesT = kLinesK + kLinesV;   // 64 + 256 per tile
+  Cursor c;
+  const char *kh, *vh;
+  size_t so0, tps, hwp;
+  int jt0, ntl, part, nparts;
+  unsigned patch;
+  __device__ inline void init(const BankView& b, const Walk& wk, const int* tpre, char* lds_base, int wave_slot) {
+    c.init(tpre, wk.t, wk.jt0 + wk.ntl - 1);
+    kh = b.kh; vh = b.vh;
+    so0 = (size_t)wk.o * b.Tcap; tps = (size_t)(b.hwp / kJT); hwp = (size_t)b.hwp;
+    jt0 = wk.jt0; ntl = wk.ntl; part = wk.pf_part; nparts = wk.pf_nparts;
+    patch = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) char*)(lds_base + kLdsBytes - 12 * 256 + wave_slot * 256));
+  }
+  // the lines of step `step`, this workgroup's share, spread over waves w = 0 .. nw - 1
+  __device__ inline void touch(int step, int w, int nw, int lane) {
+    if (nparts <= 0) return;
+    const int ja = jt0 + 2 * step;
+    if (ja >= jt0 + ntl) return;                                         // (wave-uniform)
+    const int la = c.seek(ja);
+    const char* ka = kh + ((so0 + c.tt) * hwp + (size_t)la * kJT) * kDe * sizeof(_Float16);
+    const char* va = vh + ((so0 + c.tt) * tps + la) * (size_t)(kDo * kJT * 2);
+    const int lb = c.seek(ja + 1);                                       // (clamped to the segment's last tile)
+    const char* kb2 = kh + ((so0 + c.tt) * hwp + (size_t)lb * kJT) * kDe * sizeof(_Float16);
+    const char* vb2 = vh + ((so0 + c.tt) * tps + lb) * (size_t)(kDo * kJT * 2);
+    const int nl = (2 * kLinesT + nparts - 1) / nparts;                  // lines of this workgroup
+    for (int l0 = w * 64; l0 < nl; l0 += nw * 64) {                      // (wave-uniform trip count)
+      int i = (l0 + lane) * nparts + part;
+      i = i < 2 * kLinesT ? i : part;                                    // (past the share: a duplicate of its first line)
+      const bool second = i >= kLinesT;
+      const int r = second ? i - kLinesT : i;
+      const bool isk = r < kLinesK;
+      const char* base = second ? (isk ? kb2 : vb2) : (isk ? ka : va);
+      const char* ad = base + (size_t)(isk ? r : r - kLinesK) * 128;
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(ad), "s"(patch) : "memory");
+    }
+  }
+};
+
 // ================================================================================================================
 // fp16-operand mode (RMNET_BANK_F16): hi planes only -- K, V, the query and P enter the MFMAs rounded to fp16 (11
 // significant bits), fp32 accumulate.  One MFMA term instead of three, and half the bank bytes.  The LDS slots and
@@ -827,96 +889,18 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
     }
     const float* qb = a.qk + (size_t)o * kDe * b.hw + cell;
     const float keep = qvalid ? a.qscale : 0.0f;
-    bool qover = false;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float x = qb[(size_t)(32 * ks + 8 * g + e) * b.hw] * keep;
-#ifndef BK_NO_QOVER
-        qover |= !(fabsf(x) <= 65504.0f);
-        qh[ks][e] = (_Float16)fminf(fmaxf(x, -65504.0f), 65504.0f);
-#else
-        qh[ks][e] = (_Float16)x;
-#endif
-      }
-#ifndef BK_NO_QOVER
-    if (qover && qvalid) atomicAdd(b.ovf, 1);   // (as in the split mode)
-#endif
+      for (int e = 0; e < 8; ++e) qh[ks][e] = (_Float16)(qb[(size_t)(32 * ks + 8 * g + e) * b.hw] * keep);   // (range: query_range_check)
   }
   float mref = -INFINITY, lsum = 0.0f;
   half8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (_Float16)1.0f;
 
-  // ---- L2 prefetch.  Inside the frame loop nothing of the bank is in a cache when the read starts (the convolutions
-  // between two reads stream hundreds of MB), a V fragment load is issued ONE step (~1.3 us) before its use and an HBM
-  // miss under load takes longer than that: the tile walk then runs at memory latency, not at the matrix pipe's pace
-  // (measured in the loop: 1.77 us per step against 1.30 with a warm cache).  The nqt workgroups of a column block walk
-  // the same K / V tiles in lockstep on one XCD, i.e. behind one L2: each of them touches 1/nqt of the 128-byte lines of
-  // the step BK_PF steps ahead (one dword per line) so that the demand loads of all of them hit the L2.  Every producer
-  // wave issues exactly kPfLoads loads per step (lanes beyond the share repeat the share's first line: one request), so
-  // hipcc can count them; a value is "used" (an empty asm) two steps later, i.e. the wave never waits for a load that is
-  // less than two steps old.
-  constexpr int kPfLoads = BK_PF_NLD;
-  struct PfRegs { unsigned v[kPfLoads > 0 ? kPfLoads : 1]; };
-  Cursor cp;
-  cp.init(tpre, wk.t, jt0 + ntl - 1);
-  const size_t so0p = (size_t)o * b.Tcap;
-  const size_t tiles_per_slot_p = (size_t)(b.hwp / kJT);
-  constexpr int kPfLinesK = kJT * kDe * 2 / 128, kPfLinesV = kDo * kJT * 2 / 128, kPfLinesT = kPfLinesK + kPfLinesV;   // 64 + 256 per tile
-  const int pf_np = wk.pf_nparts > 0 ? wk.pf_nparts : 1 << 20;           // (no share: every lane repeats line 0)
-  auto prefetch_step = [&](int step, PfRegs& r_) {
-    const int ja = jt0 + 2 * step;
-    const int la = cp.seek(ja);                                          // (clamped to the segment's last tile)
-    const char* ka = b.kh + ((so0p + cp.tt) * b.hwp + (size_t)la * kJT) * kDe * sizeof(_Float16);
-    const char* va = b.vh + ((so0p + cp.tt) * tiles_per_slot_p + la) * (size_t)(kDo * kJT * 2);
-    const int lb = cp.seek(ja + 1);
-    const char* kb2 = b.kh + ((so0p + cp.tt) * b.hwp + (size_t)lb * kJT) * kDe * sizeof(_Float16);
-    const char* vb2 = b.vh + ((so0p + cp.tt) * tiles_per_slot_p + lb) * (size_t)(kDo * kJT * 2);
-#pragma unroll
-    for (int k = 0; k < kPfLoads; ++k) {
-      int i = ((k * kProducers + wave) * 64 + lane) * pf_np + wk.pf_part;
-      i = i < 2 * kPfLinesT ? i : (wk.pf_part < 2 * kPfLinesT ? wk.pf_part : 0);
-      const bool second = i >= kPfLinesT;
-      const int r = second ? i - kPfLinesT : i;
-      const bool isk = r < kPfLinesK;
-      const char* base = second ? (isk ? kb2 : vb2) : (isk ? ka : va);
-      r_.v[k] = *reinterpret_cast<const unsigned*>(base + (size_t)(isk ? r : r - kPfLinesK) * 128);
-    }
-  };
-  // LDS-DMA form: the touched dword lands in a 256-byte junk patch of this wave; no register, nothing ever waits for it
-  // (hipcc does not see the load: its own counted waits only get more conservative; __syncthreads() stays a bare barrier).
-  const unsigned pf_patch = __builtin_amdgcn_readfirstlane(
-      (unsigned)(size_t)(__attribute__((address_space(3))) char*)(Kl_ + kLdsBytes - 4 * 256 + wave * 256));
-  auto prefetch_dma = [&](int step) {
-    if (wk.pf_nparts <= 0) return;
-    const int ja = jt0 + 2 * step;
-    if (ja >= jt0 + ntl) return;                                         // (wave-uniform)
-    const int la = cp.seek(ja);
-    const char* ka = b.kh + ((so0p + cp.tt) * b.hwp + (size_t)la * kJT) * kDe * sizeof(_Float16);
-    const char* va = b.vh + ((so0p + cp.tt) * tiles_per_slot_p + la) * (size_t)(kDo * kJT * 2);
-    const int lb = cp.seek(ja + 1);                                      // (clamped to the segment's last tile)
-    const char* kb2 = b.kh + ((so0p + cp.tt) * b.hwp + (size_t)lb * kJT) * kDe * sizeof(_Float16);
-    const char* vb2 = b.vh + ((so0p + cp.tt) * tiles_per_slot_p + lb) * (size_t)(kDo * kJT * 2);
-    const int nl = (2 * kPfLinesT + wk.pf_nparts - 1) / wk.pf_nparts;    // lines of this workgroup
-    for (int l0 = wave * 64; l0 < nl; l0 += kProducers * 64) {           // (wave-uniform trip count)
-      int i = (l0 + lane) * wk.pf_nparts + wk.pf_part;
-      i = i < 2 * kPfLinesT ? i : wk.pf_part;                            // (past the share: a duplicate of its first line)
-      const bool second = i >= kPfLinesT;
-      const int r = second ? i - kPfLinesT : i;
-      const bool isk = r < kPfLinesK;
-      const char* base = second ? (isk ? kb2 : vb2) : (isk ? ka : va);
-      const char* ad = base + (size_t)(isk ? r : r - kPfLinesK) * 128;
-      unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(ad), "s"(pf_patch) : "memory");
-    }
-  };
-  auto pf_use = [&](const PfRegs& r_) {
-#pragma unroll
-    for (int k = 0; k < kPfLoads; ++k) asm volatile("" :: "v"(r_.v[k]));
-  };
+  L2Prefetch pf;
+  if (BK_PF) pf.init(b, wk, tpre, Kl_, wave);
 
   struct Frags { half8 a0[4], a1[4], b0[4], b1[4]; };   // tile A cells 0-15 / 16-31, tile B cells 0-15 / 16-31
   auto k_frags = [&](Frags& f, int kslot) {             // 16 conflict-free ds_read_b128 (XOR-swizzled rows)
@@ -1001,15 +985,6 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
   S4 sp;                           // S of the step whose soft-max comes next
   Frags f;
   int nva, nvb;                    // cell counts of that step
-  PfRegs pf_pro[BK_PF > 1 ? BK_PF - 1 : 1], pf_a, pf_b;
-  if (BK_PF && BK_PF_DMA) {
-#pragma unroll 1
-    for (int s_ = 1; s_ < BK_PF; ++s_) prefetch_dma(s_);   // (step 0 and the K tiles of steps 1..4 are demand loads of the prologue)
-  } else if (BK_PF) {
-#pragma unroll
-    for (int s_ = 1; s_ < BK_PF; ++s_) prefetch_step(s_, pf_pro[s_ - 1]);   // (step 0 and the K tiles of steps 1..4 are demand loads of the prologue)
-    pf_a = pf_pro[0]; pf_b = pf_pro[0];
-  }
   __syncthreads();                                   // A: K steps 0..3 in the ring
   {
     S4 s0, s1;
@@ -1027,10 +1002,6 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
     soft_max(s1, 1);
     k_frags(f, 3);
     step_valid(2, nva, nvb);
-  }
-  if (BK_PF && !BK_PF_DMA) {
-#pragma unroll
-    for (int s_ = 1; s_ < BK_PF; ++s_) pf_use(pf_pro[s_ - 1]);
   }
   __syncthreads();                                   // B: P(0), P(1) visible; ring slot 0 free
   __syncthreads();                                   // C: K step 4 in slot 0
@@ -1065,21 +1036,15 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
 #endif
     step_valid(n + 3, nva, nvb);                     // (LDS round trips: they end under the barrier)
     pbuf = pbuf == 2 ? 0 : pbuf + 1;
-    if (BK_PF && BK_PF_DMA) {
-      prefetch_dma(n + BK_PF);
-    } else if (BK_PF) {
-      pf_use(pf_a);
-      pf_a = pf_b;
-      prefetch_step(n + BK_PF, pf_b);
-    }
+    if (BK_PF) pf.touch(n + BK_PF, wave, kProducers, lane);
     BK_STAMP();   // K frags requested
     __syncthreads();
     BK_STAMP();   // after barrier
   }
   m_out = mref * kSraw;
   l_out = lsum;
-  if (BK_PF && BK_PF_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the patch is free again; the youngest touch is BK_PF steps old)
-  else if (BK_PF) { pf_use(pf_a); pf_use(pf_b); }
+  query_range_check(b, qh, wk.qt * kQT + wave * 16 + l15 < wk.Mq);
+  if (BK_PF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the patch is free again; the youngest touch is BK_PF steps old)
   BK_STAMP();
 }
 
@@ -1165,6 +1130,12 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
     }
   };
   __syncthreads();                                   // A: K steps 0..3 in the ring
+  if (BK_PF) {                                       // (idle until B: the producers compute S(0..2), P(0), P(1))
+    L2Prefetch pf;
+    pf.init(b, wk, tpre, Kl_, wave);
+#pragma unroll 1
+    for (int s_ = 1; s_ < BK_PF; ++s_) pf.touch(s_, wave - kProducers, kConsumers, lane);   // (step 0 and the K tiles of steps 1..4 are demand loads)
+  }
   __syncthreads();                                   // B: P(0), P(1) visible; ring slot 0 free
   k_store(kr, 0);                                    // step 4
   k_load(kr, 5);
@@ -1332,8 +1303,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
 #ifndef BK_NO_TFLAG
   if (T_raw != T_ && blockIdx.x == 0 && tid == 0) atomicOr(b.ovf, kBankBadSlot);   // an out-of-range count is flagged)
 #endif
-  int* q_head = b.ovf + 16;                        // control block of the bank: static work queue (next item) ...
-  int* q_exit = b.ovf + 32;                        // ... workgroups that have left the kernel (the last one zeroes both)
+  int* q_head = b.ovf + 16;                        // control block of the bank: static work queue (next item); zeroed by the launcher before every launch
 
   // ---- launch-wide plan, computed identically by every workgroup from the device-resident boxes
   //      (no host sync)
@@ -1989,7 +1959,13 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     };
     __syncthreads();                                   // (the compute part's LDS traffic is over)
     if (tid < 16) lut[tid] = f32x4{(tid & 1) ? 1.f : 0.f, (tid & 2) ? 1.f : 0.f, (tid & 4) ? 1.f : 0.f, (tid & 8) ? 1.f : 0.f};
-    if (tid == 0) sflag = __hip_atomic_fetch_add(q_head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (a LOAD first: when the ~200 compute workgroups of a launch finish within a few microseconds of each other the queue is
+    //  usually empty already, and 200 returning atomics on one word serialise at ~88 per microsecond -- the last workgroup left
+    //  8 us after its epilogue without having served a ticket; loads of the same word do not queue up)
+    if (tid == 0) {
+      const int h = __hip_atomic_load(q_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sflag = h >= ntickets ? h : __hip_atomic_fetch_add(q_head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
     int ticket = sld(sflag);
 #if BK_CLK
@@ -2019,14 +1995,8 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     cb[3] = (long long)__builtin_amdgcn_s_memrealtime() - t_real;
   }
 #endif
-  // ---- leave: the last workgroup out zeroes the queue words for the next read (every workgroup comes through here)
-  if (tid == 0) {
-    const int gone = __hip_atomic_fetch_add(q_exit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (gone == (int)gridDim.x - 1) {
-      __hip_atomic_store(q_head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(q_exit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
+  // (the queue word is NOT reset here: the launcher clears the control block before every launch -- a last-one-out counter
+  //  was another 256 same-word atomics at the very end of the kernel)
 }
 
 }  // namespace
@@ -2137,6 +2107,9 @@ int launch_bank_main(const BankReadArgs& m, hipStream_t st) {
     a.nobj = m.no - obj0 < kMaxObj ? m.no - obj0 : kMaxObj;
     a.slot0 = bank_group_slot0(obj0, m.h * m.w);
     a.target = kSplitTargetSlots;
+    // the static work queue's word must be zero at every launch: the caller (launch_bank_read / the drop-in entry) has cleared
+    // the control block for the first group, the later groups clear it here
+    if (obj0 > 0 && hipMemsetAsync(a.b.ovf + 16, 0, 64, st) != hipSuccess) return RMNET_E_LAUNCH;
     if (m.f16)
       hipLaunchKernelGGL(bk_main<1>, dim3(a.target), dim3(kRThreads), 0, st, a);
     else

@@ -160,8 +160,7 @@ struct BankView {
   int32_t* area;   // [no][Tcap] cells inside the box of each memorised frame
   int32_t* ovf;    // control block (256 B): [0] number of 16-byte groups written (or query elements read) so far that held an element
                    // outside fp16's window, plus the sticky error bits 1 << 30 (slot / frame count out of range) and 1 << 29 (a merge
-                   // timed out); [1] merges that timed out; [16] / [32] the read kernel's static work queue (next item / workgroups
-                   // gone).  Bytes 64.. (queue words, arrival counters) are cleared by the launcher before every read
+                   // timed out); [1] merges that timed out; [16] the read kernel's static work queue (next item).  Bytes 64.. (queue words, arrival counters) are cleared by the launcher before every read
   int32_t* cnt;    // [no][nqt_max][2] (arrived, done) counters of the partials of an (object, query tile) pair
                    // (all queue words and counters are zero between reads)
   int no, Tcap, h, w, hw, hwp;
