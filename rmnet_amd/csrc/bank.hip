@@ -985,6 +985,10 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
   S4 sp;                           // S of the step whose soft-max comes next
   Frags f;
   int nva, nvb;                    // cell counts of that step
+  int nva0, nvb0, nva1, nvb1;      // (steps 0 and 1: their LDS -> SGPR round trips are taken BEFORE barrier A, while the consumers'
+  step_valid(0, nva0, nvb0);       //  first K tiles are still on their way; between A and B this wave is the workgroup's critical path)
+  step_valid(1, nva1, nvb1);
+  step_valid(2, nva, nvb);
   __syncthreads();                                   // A: K steps 0..3 in the ring
   {
     S4 s0, s1;
@@ -994,14 +998,11 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
     s_mfma(f, s1);
     k_frags(f, 2);
     s_mfma(f, sp);
-    step_valid(0, nva, nvb);
-    mask_ragged(s0, nva, nvb);
+    mask_ragged(s0, nva0, nvb0);
     soft_max(s0, 0);
-    step_valid(1, nva, nvb);
-    mask_ragged(s1, nva, nvb);
+    mask_ragged(s1, nva1, nvb1);
     soft_max(s1, 1);
     k_frags(f, 3);
-    step_valid(2, nva, nvb);
   }
   __syncthreads();                                   // B: P(0), P(1) visible; ring slot 0 free
   __syncthreads();                                   // C: K step 4 in slot 0
