@@ -354,6 +354,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the single-stream / free-running / per-kernel figures')
+    ap.add_argument('--extras-child', action='store_true',
+                    help='(internal) compute ONLY the extras block and print it: the default run takes its extras from a child process '
+                         'started this way, so that a fault in one of the many secondary configurations cannot take the headline line with it')
     ap.add_argument('--no-miopen-find', action='store_true',
                     help='leave torch.backends.cudnn.benchmark off (MIOpen immediate mode; ~5 %% slower convs)')
     ap.add_argument('--no-fuse-epilogue', action='store_true',
@@ -484,21 +487,28 @@ def main():
         # label maps to rank 0 (rmnet_amd.dist.gather_label_maps: header all_gather + one padded gather) -- timed
         # on the last frame's label maps (uint8 [1, H, W] per clip), payloads resident on the GPU.
         import torch.distributed as tdist
-        times = [None] * world
-        tdist.all_gather_object(times, float(elapsed_local))
-        labels = out.argmax(dim=1).to(torch.uint8)
-        mine = {rank * B + c: labels[c:c + 1] for c in range(B)}
-        rd.gather_label_maps(mine, world * B)                           # warm-up (connection set-up)
-        torch.cuda.synchronize()
-        rd.barrier()
-        tg = time.perf_counter()
-        got = rd.gather_label_maps(mine, world * B)
-        torch.cuda.synchronize()
-        gather_ms = rd.max_over_ranks(1e3 * (time.perf_counter() - tg))
-        if rank == 0:
-            assert sorted(got) == list(range(world * B)) and tuple(got[0].shape) == (1, H, W)
+        cdev = dev if tdist.get_backend() == 'nccl' else torch.device('cpu')
+        mine_t = torch.tensor([float(elapsed_local)], dtype=torch.float64, device=cdev)
+        all_t = [torch.zeros_like(mine_t) for _ in range(world)]
+        tdist.all_gather(all_t, mine_t)
+        times = [float(t.item()) for t in all_t]
+        gather_ms, gather_err = None, None
+        try:          # (the collective is the same call on every rank: an unsupported-op error is raised on all of them, before any traffic)
+            labels = out.argmax(dim=1).to(torch.uint8)
+            mine = {rank * B + c: labels[c:c + 1] for c in range(B)}
+            rd.gather_label_maps(mine, world * B)                           # warm-up (connection set-up)
+            torch.cuda.synchronize()
+            rd.barrier()
+            tg = time.perf_counter()
+            got = rd.gather_label_maps(mine, world * B)
+            torch.cuda.synchronize()
+            gather_ms = round(rd.max_over_ranks(1e3 * (time.perf_counter() - tg)), 3)
+            if rank == 0:
+                assert sorted(got) == list(range(world * B)) and tuple(got[0].shape) == (1, H, W)
+        except (RuntimeError, AssertionError) as exc:
+            gather_err = repr(exc)[:300]
         multi = {'per_rank_fps': [round(B * args.steps / t, 2) for t in times],
-                 'gather_ms': round(gather_ms, 3), 'gather_bytes_per_rank': int(B * H * W),
+                 'gather_ms': gather_ms, 'gather_error': gather_err, 'gather_bytes_per_rank': int(B * H * W),
                  'backend': tdist.get_backend(),
                  'note': 'per_rank_fps = clips x steps / that rank\'s own time of the timed region (value uses the max over ranks); '
                          'gather_ms = header all_gather + one padded gather of the last frame\'s uint8 label maps to rank 0, '
@@ -516,7 +526,7 @@ def main():
     # the OTHER arithmetic mode of the same kernel on the same launches (same bank, same boxes), outside the timed region
     other_mode = 'f16' if args.read_precision == 'split' else 'split'
     other_ms = None
-    if not args.no_extras:
+    if not args.no_extras and not args.extras_child:
         bank.precision = other_mode
         for i in range(3):
             eager_step(i)
@@ -561,11 +571,36 @@ def main():
             traffic_note = 'profiles/' + tname + ' is from other kernel sources or another workload: not reported'
 
     extras = None
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras and not args.extras_child:
+        # The extras (single stream, HIP-graph replay, free-running clip, other configurations, every kernel alone, profiler shares) run
+        # in a CHILD process: they launch a dozen secondary configurations, and a GPU fault in any of them -- round 4 met one in the
+        # runtime's memset node under graph replay -- would otherwise kill this process before the headline line is printed.
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), '--extras-child', '--steps', '3', '--warmup', '2', '--no-cpu-baseline',
+               '--clips-per-gpu', str(args.clips_per_gpu), '--read-precision', requested_precision]
+        for flag, on in (('--no-miopen-find', args.no_miopen_find), ('--no-fuse-epilogue', args.no_fuse_epilogue), ('--fold-bn', args.fold_bn),
+                         ('--channels-last', args.channels_last)):
+            if on:
+                cmd.append(flag)
+        _phase('extras: child process')
+        try:
+            env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+            lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{"extras"')]
+            if res.returncode == 0 and lines:
+                extras = json.loads(lines[-1])['extras']
+            else:
+                extras = {'error': 'extras child rc=%s: %s' % (res.returncode, (res.stderr or '')[-400:])}
+        except Exception as exc:                           # (timeout, spawn failure)
+            extras = {'error': 'extras child: %r' % (exc,)}
+        _phase('extras: child done')
+    elif rank == 0 and world == 1 and args.extras_child:
         extras = {}
         # ---- who owns the timed region's GPU time: hand-written kernels (namespace rmnet) vs everything else (MIOpen / rocBLAS /
         #      torch element-wise), from torch.profiler's device-side kernel records of three steps of the same loop
         try:
+            if os.environ.get('BENCH_NO_PROFILER') == '1':
+                raise RuntimeError('skipped (BENCH_NO_PROFILER=1)')
             from torch.profiler import ProfilerActivity, profile
             with profile(activities=[ProfilerActivity.CUDA]) as prof:
                 for i in range(3):
@@ -713,6 +748,9 @@ def main():
         extras['kernels'] = kernel_figures(dev, events)
         _phase('extras done')
 
+    if args.extras_child:
+        print(json.dumps({'extras': extras}), flush=True)
+        return
     if rank == 0:
         line = {
             'metric': 'frames/sec at 480p, 1 object, T=5 memory; memory-read HBM GB/s vs peak',

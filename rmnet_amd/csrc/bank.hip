@@ -2040,6 +2040,20 @@ __global__ __launch_bounds__(256) void bk_chain(const ChainArgs c) {
 }
 }  // namespace
 
+// Clears `nwords` int32 of a bank's control block.  A KERNEL, not hipMemsetAsync: as a memset node of a captured HIP graph the
+// runtime's fill faulted on the second replay about every other run (MI355X, ROCm 7.2: `Memory access fault by GPU`, found by
+// bench.py's graph section in round 4; `tools/repro_single.py GRAPH=1`), a kernel node of the same graph never did.
+namespace {
+__global__ __launch_bounds__(256) void bk_ctl_clear(int32_t* w, int nwords) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nwords; i += gridDim.x * 256) w[i] = 0;
+}
+}  // namespace
+int launch_bank_ctl_clear(int32_t* words, int nwords, hipStream_t st) {
+  if (nwords <= 0) return RMNET_OK;
+  hipLaunchKernelGGL(bk_ctl_clear, dim3(nwords > 4096 ? 8 : 1), dim3(256), 0, st, words, nwords);
+  return check_launch();
+}
+
 int bank_chain_max_chunks() { return kChainMax; }
 int bank_max_frames_per_launch() { return kMaxT; }
 
@@ -2110,7 +2124,8 @@ int launch_bank_main(const BankReadArgs& m, hipStream_t st) {
     a.target = kSplitTargetSlots;
     // the static work queue's word must be zero at every launch: the caller (launch_bank_read / the drop-in entry) has cleared
     // the control block for the first group, the later groups clear it here
-    if (obj0 > 0 && hipMemsetAsync(a.b.ovf + 16, 0, 64, st) != hipSuccess) return RMNET_E_LAUNCH;
+    if (obj0 > 0)
+      if (int e = launch_bank_ctl_clear(a.b.ovf + 16, 16, st)) return e;
     if (m.f16)
       hipLaunchKernelGGL(bk_main<1>, dim3(a.target), dim3(kRThreads), 0, st, a);
     else

@@ -274,6 +274,7 @@ struct BankReadArgs {
   float* ml_out = nullptr;    // optional [no][2][h*w]: soft-max state of the merged query cells (bank.hip: bk_chain)
 };
 int bank_max_frames_per_launch();
+int launch_bank_ctl_clear(int32_t* words, int nwords, hipStream_t st);   // (a kernel: see bank.hip)
 int bank_chain_max_chunks();
 int launch_bank_ml_fill(float* ml, int no, int hw, float l0, hipStream_t st);
 int launch_bank_chain(float* out, const float* tmp, const float* ml, int no, int hw, int nchunk, hipStream_t st);

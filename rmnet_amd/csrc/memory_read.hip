@@ -820,7 +820,7 @@ int launch_memory_read(const MemReadArgs& m, hipStream_t st) {
     if (via_bank) {
       const BankView b = bank_view(bank, m.no, m.T, m.h, m.w);
       // control block of the transient bank: the overflow word and the pairs' arrival tickets (the workspace is arbitrary memory)
-      if (hipMemsetAsync(b.ovf, 0, bank_ctl_bytes(m.no, m.h, m.w), st) != hipSuccess) return RMNET_E_LAUNCH;
+      if (int e = launch_bank_ctl_clear(b.ovf, (int)(bank_ctl_bytes(m.no, m.h, m.w) / 4), st)) return e;
       if (int e = launch_bank_stage(bank, m.no, m.T, m.h, m.w, 0, m.T, m.mk, m.mv, mk_cs, mk_os, mv_cs, mv_os,
                                     m.mem_rects, st))
         return e;
@@ -918,11 +918,11 @@ int launch_bank_read(BankReadArgs& m, hipStream_t st) {
   if (!m.ws || m.ws_bytes < bank_read_ws_bytes_T(m.no, m.h, m.w, m.T)) return RMNET_E_WORKSPACE;
   // The read kernel's queue words and arrival counters must be zero when it starts.  Every read leaves them so, but an
   // aborted launch (or a merge that timed out) would poison every later read of the bank: clear them per call
-  // (cdna_hip_programming.md section 6 Guideline 16, "re-initialise every call"; a memset node under graph capture).  The first
+  // (cdna_hip_programming.md section 6 Guideline 16, "re-initialise every call"; a small kernel: launch_bank_ctl_clear).  The first
   // 64 bytes (overflow / time-out words) are the bank's own sticky state and stay.
   const BankView b = bank_view(m.bank, m.no, m.Tcap, m.h, m.w);
 #ifndef RMNET_NO_CTL_MEMSET
-  if (hipMemsetAsync(reinterpret_cast<char*>(b.ovf) + 64, 0, bank_ctl_bytes(m.no, m.h, m.w) - 64, st) != hipSuccess) return RMNET_E_LAUNCH;
+  if (int e = launch_bank_ctl_clear(b.ovf + 16, (int)(bank_ctl_bytes(m.no, m.h, m.w) / 4) - 16, st)) return e;
 #endif
   // ONE kernel: bk_main writes the q_val half and the masked cells while it waits for its plan, reads, and the last
   // arriver of every (object, query tile) pair merges the pair's partials and writes the read-out (bank.hip).
@@ -947,7 +947,8 @@ int launch_bank_read(BankReadArgs& m, hipStream_t st) {
       r.out = c == 0 ? out : tmp + (size_t)(c - 1) * m.no * 2 * kDo * hw;
       r.ml_out = ml + (size_t)c * m.no * 2 * hw;
       if (int e = launch_bank_ml_fill(r.ml_out, m.no, hw, (float)r.T * (float)hw, st)) return e;
-      if (c > 0 && hipMemsetAsync(reinterpret_cast<char*>(b.ovf) + 64, 0, bank_ctl_bytes(m.no, m.h, m.w) - 64, st) != hipSuccess) return RMNET_E_LAUNCH;
+      if (c > 0)
+        if (int e = launch_bank_ctl_clear(b.ovf + 16, (int)(bank_ctl_bytes(m.no, m.h, m.w) / 4) - 16, st)) return e;
       if (int e = bank_read_one(r, st)) return e;
     }
     if (int e = launch_bank_chain(out, tmp, ml, m.no, hw, nchunk, st)) return e;
