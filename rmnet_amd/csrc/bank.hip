@@ -1209,8 +1209,8 @@ __device__ inline PairSlots pair_slots(int sb, int nqt, const BankChunks& bc, in
   PairSlots r{sb + qt, bc.nfull, nqt, 0, bc.nfull, 0};
   if (bc.R > 0) {
     const int v0 = qt * (bc.R + bc.sc);                                   // the pair on the virtual line
-    r.cf = v0 / bc.C;
-    const int cl = (v0 + bc.R - 1) / bc.C;                                   // remainder chunks touching it
+    r.cf = plan_div(v0, bc.C);
+    const int cl = plan_div(v0 + bc.R - 1, bc.C);                            // remainder chunks touching it
     r.b0 = sb + nqt * bc.nfull + r.cf + qt;
     r.count += cl - r.cf + 1;
   }
@@ -1301,9 +1301,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     spec_ar = b.area[(size_t)(a.obj0 + wave) * b.Tcap + lane0];
   const int T_raw = a.T + (a.T_dev ? __builtin_amdgcn_readfirstlane(*a.T_dev) : 0);
   const int T_ = min(max(T_raw, 1), a.Tmax);         // memorised frames to read (the clamp is memory safety only:
-#ifndef BK_NO_TFLAG
   if (T_raw != T_ && blockIdx.x == 0 && tid == 0) atomicOr(b.ovf, kBankBadSlot);   // an out-of-range count is flagged)
-#endif
   int* q_head = b.ovf + 16;                        // control block of the bank: static work queue (next item); zeroed by the launcher before every launch
 
   // ---- launch-wide plan, computed identically by every workgroup from the device-resident boxes
@@ -1314,11 +1312,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   const bool fastplan = ng <= kProducers + kConsumers && T_ <= RMNET_WAVE;
   int my_ar = 0;
   if (fastplan) {
-#ifdef BK_NO_SPEC
-    if (wave < ng && lane0 < T_) my_ar = b.area[(size_t)(a.obj0 + wave) * b.Tcap + lane0];
-#else
     if (wave < ng && lane0 < T_) my_ar = spec_ar;
-#endif
   } else if (tid < ng) {
     o_njt[tid] = 0; o_m[tid] = 0;
   }
@@ -1383,7 +1377,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
       const int nrem = R > 0 && nqt > 0 ? fdiv(nqt * (R + kSC) - kSC + c - 1, c, rc) : 0;
       return nqt * nfull + nrem;
     };
-    int C0 = max((W + target - 1) / target, bank_chunk_min(njt_max));
+    int C0 = max(W < (1 << 22) ? plan_div(W + target - 1, target) : (W + target - 1) / target, bank_chunk_min(njt_max));
     C0 = (C0 + kCq - 1) / kCq * kCq;
     for (int it = 0; it < 256; ++it) {
       const int c1 = next_c(C0), c2 = next_c(c1), c3 = next_c(c2);
@@ -1570,9 +1564,6 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
           __builtin_amdgcn_s_sleep(4);
           if (++polls > (1 << 22)) { gave_up = true; break; }
         }
-#ifdef BK_NO_TMO
-        gave_up = false;
-#endif
         if (gave_up) {   // (cannot happen: the others hold a ticket and only store.  Never hang the GPU: count it in the time-out
           atomicAdd(b.ovf + 1, 1);                                          // word, make the bank say "do not trust me" and leave
           atomicOr(b.ovf, kBankTimeout);                                    // the counters alone -- late arrivers may still bump them;
@@ -1749,7 +1740,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   };
 
   if (cl < nqt * bc.nfull) {          // aligned chunk: (column block, query tile), one segment
-    const int blk = cl / nqt;
+    const int blk = plan_div(cl, nqt);
     wk.qt = cl - blk * nqt;
     wk.jt0 = blk * bc.Cb;
     wk.ntl = bc.Cb;
@@ -1762,7 +1753,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   const int cr = cl - nqt * bc.nfull;
   const int u0 = cr * C, u1 = u0 + C, span = bc.R + bc.sc;
   bool first = true;
-  for (int qt = u0 / span; qt < nqt && qt * span < u1; ++qt) {
+  for (int qt = plan_div(u0, span); qt < nqt && qt * span < u1; ++qt) {
     const int j0 = max(u0 - qt * span, 0), j1 = min(u1 - qt * span, bc.R);   // tiles of pair qt inside the chunk
     if (j1 <= j0) continue;
     wk.qt = qt;
@@ -1772,7 +1763,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     wk.pf_part = 0; wk.pf_nparts = BK_PF_REM ? 1 : 0;
     if (!first) __syncthreads();      // the previous segment's LDS (K ring, P, alpha, epilogue scratch) is free
     first = false;
-    run_segment(bc.nfull + cr - (qt * span) / C);
+    run_segment(bc.nfull + cr - plan_div(qt * span, C));
   }
   };   // compute()
   if ((int)blockIdx.x < nchunks) {

@@ -216,13 +216,25 @@ constexpr int kSegCost = RMNET_SEG_COST;
 #define RMNET_SEG_COST_F16 12   // fp16-operand mode: a tile costs a third, a segment's fixed part does not
 #endif
 constexpr int kSegCostF16 = RMNET_SEG_COST_F16;
+// Division of the launch plan's small non-negative integers (all < 2^22).  On the device hipcc expands an integer division by a
+// run-time divisor into ~35 instructions, and the plan + the chunk lookup of bk_main do a dozen of them on the critical path of
+// every workgroup; an fp32 reciprocal is off by at most one there, and the remainder fixes it up (exact, ~8 instructions).
+__host__ __device__ inline int plan_div(int x, int c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int q = (int)((float)x * __builtin_amdgcn_rcpf((float)c));
+  const int r = x - q * c;
+  return q + (r >= c ? 1 : 0) - (r < 0 ? 1 : 0);
+#else
+  return x / c;
+#endif
+}
 struct BankChunks { int C, Cb, nfull, R, nrem, nch, sc; };
 __host__ __device__ inline BankChunks bank_chunks(int nqt, int njt, int C, int segcost = kSegCost, bool own_blocks = false) {
   BankChunks k;
   k.C = C;
   k.sc = segcost;
   k.Cb = C;                          // length of an aligned column block
-  k.nfull = njt / C;
+  k.nfull = plan_div(njt, C);
   k.R = njt - k.nfull * C;
   // An object with no more tiles than a chunk is ONE column block of its own length: nqt single-segment chunks that
   // walk the same tiles in lockstep.  As a "remainder" its pairs would be cut at shifted positions, every workgroup
@@ -231,7 +243,7 @@ __host__ __device__ inline BankChunks bank_chunks(int nqt, int njt, int C, int s
   // `own_blocks` is a launch-wide decision of the plan: C is found WITHOUT it (the chunk count then falls as C grows, so
   // a launch with more pairs than workgroups still fits); it is switched on if the launch still fits with it.
   if (own_blocks && njt > 0 && njt <= C) { k.Cb = njt; k.nfull = 1; k.R = 0; }
-  k.nrem = k.R > 0 && nqt > 0 ? (nqt * (k.R + segcost) - segcost + C - 1) / C : 0;   // (no query tile: no chunk)
+  k.nrem = k.R > 0 && nqt > 0 ? plan_div(nqt * (k.R + segcost) - segcost + C - 1, C) : 0;   // (no query tile: no chunk)
   k.nch = nqt * k.nfull + k.nrem;
   return k;
 }

@@ -921,7 +921,7 @@ int launch_bank_read(BankReadArgs& m, hipStream_t st) {
   // (cdna_hip_programming.md section 6 Guideline 16, "re-initialise every call"; a small kernel: launch_bank_ctl_clear).  The first
   // 64 bytes (overflow / time-out words) are the bank's own sticky state and stay.
   const BankView b = bank_view(m.bank, m.no, m.Tcap, m.h, m.w);
-#ifndef RMNET_NO_CTL_MEMSET
+#ifndef RMNET_NO_CTL_CLEAR   // (experiments only)
   if (int e = launch_bank_ctl_clear(b.ovf + 16, (int)(bank_ctl_bytes(m.no, m.h, m.w) / 4) - 16, st)) return e;
 #endif
   // ONE kernel: bk_main writes the q_val half and the masked cells while it waits for its plan, reads, and the last
