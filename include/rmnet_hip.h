@@ -199,7 +199,7 @@ int rmnet_bank_read_f32_at(void *bank, int no, int Tcap, int h, int w, int T, co
                            const float *q_key, const float *q_val, const int32_t *qry_rects,
                            float *mem_val, void *workspace, size_t workspace_bytes, void *stream,
                            void *ev_start, void *ev_mid, void *ev_end);
-/* workspace of a read: the first form covers T <= 2048 frames, the _T form any T (ABI v4, chunked reads) */
+/* workspace of a read: the first form covers T <= 2048 frames, the _for form any T (ABI v4, chunked reads) */
 size_t rmnet_bank_read_workspace_bytes(int no, int h, int w);
 size_t rmnet_bank_read_workspace_bytes_for(int no, int h, int w, int T);
 int rmnet_bank_read_f32(void *bank, int no, int Tcap, int h, int w, int T,

@@ -1,6 +1,8 @@
 #!/bin/bash
 # The round's record in one gpurun call: GPU tests, default bench line, its rocprofv3 kernel table, PMC traffic (both modes), SQ counters,
 # the hand-written kernels one by one under rocprofv3, stress tests, the DPP helper check, the loop time line.
+# Before the call (build container): tools/build_variant.sh finalclk -DBK_CLK=1; cp rmnet_amd/librmnet_hip.so build/variants/lib_main.so;
+# hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/dpp_check.hip -o tools/ubench/dpp_check   (build/ and the binary are git-ignored, they travel with gpurun)
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 ROOT=$PWD
 out=gpurun_out/${1:-r04_final}
