@@ -1641,7 +1641,7 @@ def test_f16_mode_whole_clip_meets_the_iou_bar(oracle_mod):
 
 
 _CALIB_CASES = {   # objects, H, W, memorize_every, seed, blob size, frames
-    '1obj-480p': (1, 480, 854, 5, 1, 2.1, 14),
+    '1obj-480p': (1, 480, 854, 5, 1, 2.1, 12),
     '3obj-480p': (3, 480, 854, 5, 3, 1.1, 20),
     '5obj-480p': (5, 480, 854, 2, 4, 1.6, 20),     # (the configuration on which the fp16-operand loop misses the bar: 0.9989)
 }   # (the 720p 3-object clip and the 30-frame runs are in profiles/r04_iou_calibration.md: tools/iou_calib.py; not re-run by the suite)
@@ -1650,7 +1650,7 @@ _CALIB_CASES = {   # objects, H, W, memorize_every, seed, blob size, frames
 @pytest.mark.parametrize('case', sorted(_CALIB_CASES))
 def test_iou_bar_against_the_cpu_path_on_long_clips(case, oracle_mod):
     """The north star's bar -- mask IoU within 1e-3 of the CPU path -- measured against THAT path (OracleRMNet on the host
-    cores) on 20-frame clips with 3 / 5 objects (14 frames with one) at 480x854, for the GPU loop in its default
+    cores) on 20-frame clips with 3 / 5 objects (12 frames with one) at 480x854, for the GPU loop in its default
     configuration ('auto': fp16-operand read for one object per clip, split-fp16 for several), with the exact-fp32 read and
     with the fp16-operand read forced.  Bars: default and exact >= 0.999 per object on every clip; fp16 forced >= 0.999 with
     one object (probabilities within 1e-3 as well) and >= 0.998 otherwise (measured 0.9986-0.9995 on these procedural random
@@ -1663,8 +1663,8 @@ def test_iou_bar_against_the_cpu_path_on_long_clips(case, oracle_mod):
     assert prod.read_precision == 'auto'
     frames, masks, flows, n_objects = synthetic_clip(N, n_obj + 1, H, W, seed=seed, size=size)
     threads = torch.get_num_threads()
-    torch.set_num_threads(min(32, threads))
-    oracle_mod.set_num_threads(min(32, threads))
+    torch.set_num_threads(min(16, threads))           # (the CPU path is fastest at 16 threads on the GPU box: bench.py cpu_baseline.sweep)
+    oracle_mod.set_num_threads(min(16, threads))
     try:
         with torch.no_grad():
             est_cpu = ref(frames, masks, flows, n_objects, every)
