@@ -68,3 +68,22 @@ if raw[:, 1].max() > 0:
     print('walk us by XCD: ' + '  '.join('%d: med %.1f max %.1f' % (x, np.median(walk[comp & (np.arange(256) % 8 == x)]), walk[comp & (np.arange(256) % 8 == x)].max()) for x in range(8)))
     cyc = raw[:, 0] / (raw[:, 1] * 10.0 + 1e-9)
     print('clock GHz: med %.2f min %.2f max %.2f' % (np.median(cyc[comp]), cyc[comp].min(), cyc[comp].max()))
+    if os.environ.get('EPILOGUE') == '1':   # a build with the (uncommitted) epilogue stamps: col 0 = E2 passed / published, 2 = nsp*1000 + ticket*10 + role, 4 = merged, 7 = stores issued
+        code = raw[:, 2]
+        role = code % 10
+        nsp = code // 1000
+        for r, name in ((1, 'last arrivers'), (0, 'early arrivers'), (2, 'single segment')):
+            sel = comp & (role == r) & (nsp > 0)
+            if not sel.any():
+                continue
+            if r == 0:
+                print('%s (%d): walk over %s; published %s; left %s' % (name, sel.sum(), st(6, sel), st(0, sel), st(3, sel)))
+            else:
+                print('%s (%d, nsp %s): walk over %s; partials there %s; merged %s; stores issued %s; left %s'
+                      % (name, sel.sum(), np.bincount(nsp[sel]).tolist(), st(6, sel), st(0, sel), st(4, sel), st(7, sel), st(3, sel)))
+                d = us[sel]
+                print('   deltas: walk->there %.1f  there->merged %.1f  merged->stored %.1f  stored->left %.1f (medians)'
+                      % (np.median(d[:, 0] - d[:, 6]), np.median(d[:, 4] - d[:, 0]), np.median(d[:, 7] - d[:, 4]), np.median(d[:, 3] - d[:, 7])))
+                worst = np.argsort(-d[:, 3])[:6]
+                for w in worst:
+                    print('   late: nsp %d walk %.1f there %.1f merged %.1f stored %.1f left %.1f' % (nsp[sel][w], d[w, 6], d[w, 0], d[w, 4], d[w, 7], d[w, 3]))
