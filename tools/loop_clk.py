@@ -45,6 +45,8 @@ for i in range(3 + steps):
 torch.cuda.synchronize()
 us_ = [ev.elapsed_ms(ev.ev[3 * i], ev.ev[3 * i + 1]) * 1e3 - floor for i in range(steps)]
 print('in-loop bk_main (%s): avg %.2f min %.2f max %.2f us' % (prec, np.mean(us_), np.min(us_), np.max(us_)))
+if os.environ.get('DIST') == '1':
+    print('   per launch, sorted: ' + ' '.join('%.1f' % x for x in sorted(us_)))
 no = B
 plan_end = no * 12 * 4
 base = nb - 16384 - ((plan_end + 255) // 256 * 256)
