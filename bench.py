@@ -347,6 +347,22 @@ def _phase(name):
         print('[bench %7.1f s] %s' % (time.perf_counter() - _T_START, name), file=sys.stderr, flush=True)
 
 
+def _self_launch(n):
+    """``python bench.py --gpus N`` without a launcher: re-execute this command line as N ranks under
+    ``torch.distributed.run`` (rendezvous on 127.0.0.1 at a free port; HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver only has
+    dmabuf IPC, RCCL needs it) and pass the ranks' output through -- rank 0 prints the one JSON line.  Returns the exit code."""
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -384,6 +400,10 @@ def main():
     from rmnet_amd.synthetic import synthetic_clip
     from rmnet_amd.tiny_flownet import TinyFlowNet
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # started from a plain shell (`python bench.py --gpus N`): become the launcher of N ranks of this same command line
+        # (one process per GPU, RCCL over xGMI) and relay rank 0's JSON line
+        sys.exit(_self_launch(args.gpus))
     rank, world, local = rd.init_from_env(args.dist_backend)
     if args.dist_backend == 'gloo':
         local = local % max(torch.cuda.device_count(), 1)

@@ -25,9 +25,11 @@
 extern "C" {
 #endif
 
-#define RMNET_ABI_VERSION 4   /* 2: rmnet_bank_read_f32 takes a mutable bank; rmnet_bank_area_offset.  3: RMNET_MR_F16 / RMNET_BANK_F16,
+#define RMNET_ABI_VERSION 5   /* 2: rmnet_bank_read_f32 takes a mutable bank; rmnet_bank_area_offset.  3: RMNET_MR_F16 / RMNET_BANK_F16,
                                * rmnet_bank_read_f32_at takes flags.  4: banks of any Tcap, chunked reads of T > 2048 (rmnet_bank_read_workspace_bytes_for);
-                               * the read counts out-of-window query elements; sticky error bits + time-out word behind the overflow word */
+                               * the read counts out-of-window query elements; sticky error bits + time-out word behind the overflow word.
+                               * 5: RMNET_MR_MIXED / RMNET_BANK_MIXED (logits in three split-fp16 terms, O = V P in one); a pair whose merge timed out is
+                               * written as NaN; the overflow word is a zero / non-zero flag, not an element count */
 
 enum {
   RMNET_OK = 0,
@@ -121,6 +123,12 @@ int rmnet_boxes_to_cell_rects_i32(const int32_t *bboxes, int n_boxes, int k_per_
 #define RMNET_MR_EXACT_FP32 2    /* fast shape only: skip the split-fp16 bank, run the exact-fp32 MFMA kernel */
 #define RMNET_MR_F16 4           /* fast shape only: fp16 operands (hi planes of the bank), fp32 accumulate */
 #define RMNET_BANK_F16 4         /* the same switch for rmnet_bank_read_f32_at */
+#define RMNET_MR_MIXED 8         /* fast shape only: the logits S = K^T q in the default's three split-fp16 terms (fp32-class), the soft-max
+                                  * weights and the values rounded to fp16 for O = V P (one term, hi plane of V).  Error of a read-out:
+                                  * P's and V's roundings only (2^-12 relative each, averaged over the cells that contribute) -- the |S| 2^-11
+                                  * weight error of RMNET_MR_F16, which is what costs mask IoU on multi-object clips, is gone.  About the
+                                  * speed of RMNET_MR_F16.  Mutually exclusive with it. */
+#define RMNET_BANK_MIXED 8       /* the same switch for rmnet_bank_read_f32_at */
 
 size_t rmnet_memory_read_workspace_bytes(int no, int De, int Do, int T, int h, int w, int flags);
 int rmnet_memory_read_f32(const float *m_key, const float *m_val, const float *q_key,
@@ -172,16 +180,18 @@ int rmnet_memory_read_f32_ev(const float *m_key, const float *m_val, const float
  *       silently), so "overflow word == 0 after the read" covers both sides.  The word also carries two sticky error bits:
  *       1 << 30 = an append / read through a device counter hit a slot or frame count outside [0, Tcap] (nothing was written /
  *       the count was clamped), 1 << 29 = a merge inside a read gave up waiting for another workgroup's partial (cannot happen on
- *       a healthy device; the int32 right behind the overflow word counts these time-outs separately).  Any non-zero value means:
- *       do not trust the reads of this bank, re-run exactly.
+ *       a healthy device; the int32 right behind the overflow word counts these time-outs separately; the read-out of the pair whose
+ *       merge gave up is written as NaN, never as a partially merged value).  Any non-zero value means: do not trust the reads of
+ *       this bank, re-run exactly.  The word is a FLAG (zero / non-zero), not a count of elements: the read adds to it once per
+ *       (query element, segment of the launch plan) that sees it, the append once per 16-byte group.
  *       rmnet_bank_area_offset(): byte offset of the int32 [no][Tcap] table of cells stored per slot (accounting).
  *       One launch reads at most 2048 slots (LDS prefix arrays).  Longer memories (models/rmnet.py:416-426 has no bound; ABI v4):
  *       a bank may have any Tcap; rmnet_bank_read_f32 / _at with T > 2048 (host-side T only: T_dev must be NULL for such a bank)
  *       read it in chunks of 2048 slots and merge the chunks' read-outs by their soft-max state (m, l) -- the same merge the
  *       kernel applies to the partial results of one launch -- in a workspace of rmnet_bank_read_workspace_bytes_for(...) bytes.
  * rmnet_bank_read_f32_at(..., flags): 0 = the arithmetic above; RMNET_BANK_F16 = hi planes only (see RMNET_MR_F16: fp16
- *       operands, fp32 accumulate, ~2^-11 relative, 1.5-2x as fast).  The bank is the same either way: a clip
- *       can be memorised once and read in both modes.
+ *       operands, fp32 accumulate, ~2^-11 relative, 1.5-2x as fast); RMNET_BANK_MIXED = logits in three terms, O = V P in one
+ *       (see RMNET_MR_MIXED).  The bank is the same in every mode: a clip can be memorised once and read in all three.
  * ------------------------------------------------------------------------------------------- */
 size_t rmnet_bank_bytes(int no, int Tcap, int h, int w);
 size_t rmnet_bank_overflow_offset(int no, int Tcap, int h, int w);

@@ -169,21 +169,25 @@ def memory_read(m_key, m_val, q_key, q_val, mem_rects=None, qry_rects=None, want
 
 BANK_F16 = 4                      # include/rmnet_hip.h: RMNET_BANK_F16 (== RMNET_MR_F16)
 MR_F16 = 4
+BANK_MIXED = 8                    # RMNET_BANK_MIXED (== RMNET_MR_MIXED)
+MR_MIXED = 8
+_PRECISION_FLAGS = {'split': 0, 'f16': BANK_F16, 'mixed': BANK_MIXED}
 
 
 def _precision(p):
     """'split': K, V, q and P enter the MFMAs as fp16 hi/lo pairs, three terms, fp32-class accuracy (default).
+    'mixed': the logits K^T q in those three terms, the soft-max weights and V rounded to fp16 for V P (one term).
     'f16': hi planes only -- fp16 operands, fp32 accumulate, about 2^-11 relative (include/rmnet_hip.h)."""
-    if p not in ('split', 'f16'):
-        raise ValueError("precision must be 'split' or 'f16'")
+    if p not in _PRECISION_FLAGS:
+        raise ValueError("precision must be 'split', 'mixed' or 'f16'")
     return p
 
 
 def _loop_precision(p):
-    """Arithmetic of the frame loop's bank read: 'auto' (default), 'f16' or 'split'.  'auto' picks per clip batch:
-    'f16' when every clip has ONE object, 'split' otherwise -- see RMNet.__init__ and profiles/r04_iou_calibration.md."""
-    if p not in ('auto', 'split', 'f16'):
-        raise ValueError("read_precision must be 'auto', 'split' or 'f16'")
+    """Arithmetic of the frame loop's bank read: 'auto' (default), 'split', 'mixed' or 'f16' -- see RMNet.__init__ and
+    profiles/r05_iou_calibration.md for what 'auto' picks and why."""
+    if p not in ('auto', 'split', 'mixed', 'f16'):
+        raise ValueError("read_precision must be 'auto', 'split', 'mixed' or 'f16'")
     return p
 
 
@@ -196,7 +200,7 @@ class MemoryBank:
         lib = _lib.load()
         self.no, self.capacity, self.h, self.w = int(no), int(capacity), int(h), int(w)
         self.device = torch.device(device)
-        self.precision = _precision(precision)        # arithmetic of ``read``: 'split' (fp32-class, default) or 'f16'
+        self.precision = _precision(precision)        # arithmetic of ``read``: 'split' (fp32-class, default), 'mixed' or 'f16'
         nb = lib.rmnet_bank_bytes(self.no, self.capacity, self.h, self.w)
         if nb == 0:
             raise RuntimeError('invalid bank geometry')
@@ -280,6 +284,9 @@ class MemoryBank:
         staged one): the call a captured graph replays.  A bank of more than 2048 slots is read in chunks planned on the
         host (csrc/memory_read.hip: launch_bank_read), so there the host's own count is used."""
         if self.capacity > BANK_MAX_SLOTS:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('MemoryBank.read_staged() of a bank of more than %d slots inside a HIP graph capture: the chunked '
+                                   'read is planned on the host, a replay would keep reading the frame count of the capture' % BANK_MAX_SLOTS)
             return self.read(self.committed + 1, q_key, q_val, qry_rects, out=out, events=events, ws=ws)
         return self.read(1, q_key, q_val, qry_rects, out=out, events=events, ws=ws, _t_dev=self.n_dev)
 
@@ -300,7 +307,7 @@ class MemoryBank:
                 ws = _ws(lib.rmnet_bank_read_workspace_bytes_for(self.no, self.h, self.w, int(T)), self.device)
             ev = [ctypes.c_void_p(e) if e else None for e in (events or (None, None, None))]
             rc = lib.rmnet_bank_read_f32_at(_ptr(self.blob), self.no, self.capacity, self.h, self.w, int(T), _ptr(_t_dev),
-                                            BANK_F16 if self.precision == 'f16' else 0, _ptr(q_key), _ptr(q_val), _ptr(qry_rects), _ptr(out), _ptr(ws),
+                                            _PRECISION_FLAGS[self.precision], _ptr(q_key), _ptr(q_val), _ptr(qry_rects), _ptr(out), _ptr(ws),
                                             ws.numel(), _stream(self.device), ev[0], ev[1], ev[2])
         _lib.check(rc, 'rmnet_bank_read_f32_at')
         return out
@@ -335,18 +342,11 @@ class TensorBank:
         return 0
 
     def timeout_count(self):
-        """Merges of a read that gave up waiting for another workgroup's partial (the int32 behind the overflow word).  Always 0
-        on a healthy device; a non-zero value also sets a sticky bit in the overflow word.  Synchronises the stream."""
-        off = _lib.load().rmnet_bank_overflow_offset(self.no, self.capacity, self.h, self.w)
-        return int(self.blob[off + 4:off + 8].view(torch.int32).item())
+        """(MemoryBank's interface: the exact-fp32 kernels have no cross-workgroup merge that could time out.)"""
+        return 0
 
     def assert_synced(self):
-        """Debug aid: the host mirror ``committed`` and the device counter ``n_dev`` agree (they only move together in
-        ``commit``; a captured ``frame_step(commit=True)`` or a foreign write to either would desynchronise them silently --
-        the kernels flag an out-of-range slot in the overflow word, an in-range wrong slot only this check finds).  Synchronises."""
-        n = int(self.n_dev.item())
-        if n != self.committed:
-            raise RuntimeError('MemoryBank: device frame counter %d != host counter %d' % (n, self.committed))
+        """(MemoryBank's interface: there is no device-resident frame counter here.)"""
 
     def stage(self, k4, v4, rects):
         if self.committed >= self.capacity:

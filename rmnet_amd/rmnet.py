@@ -49,13 +49,13 @@ class MemoryReader(nn.Module):
     def __init__(self, return_affinity=False, precision='split'):
         super().__init__()
         self.return_affinity = return_affinity
-        self.precision = ops._precision(precision)     # 'f16': fp16 operands, 1.5-2x as fast, ~2^-11 relative (ops.MR_F16)
+        self.precision = ops._precision(precision)     # 'mixed' / 'f16': see ops._precision (ops.MR_MIXED, ops.MR_F16)
 
     def forward(self, m_key, m_val, q_key, q_val, mem_rects=None, qry_rects=None, T=None):
         return ops.memory_read(m_key.contiguous(), m_val.contiguous(), q_key.contiguous(),
                                q_val.contiguous(), mem_rects, qry_rects,
                                want_p=self.return_affinity, T=T,
-                               flags=ops.MR_F16 if self.precision == 'f16' else 0)
+                               flags=ops._PRECISION_FLAGS[self.precision])
 
 
 class RMNet(nn.Module):
@@ -378,7 +378,8 @@ class RMNet(nn.Module):
         ctx = self._ClipContext(self, B, K, H, W, n_max, dev)
         bank = self.new_bank(ctx, sum(1 for j in commit if j <= N - 2) + 1, exact=_exact)
 
-        use_graph = bool(graph) and isinstance(bank, ops.MemoryBank)
+        # (a bank of more than one launch's frames is read in host-planned chunks: its frame count would be baked into the capture)
+        use_graph = bool(graph) and isinstance(bank, ops.MemoryBank) and bank.capacity <= ops.BANK_MAX_SLOTS
         replay = None
         for t in range(1, N):
             if use_graph and t >= 2:

@@ -32,7 +32,7 @@ def test_library_builds_and_exports_every_header_symbol():
 def test_error_strings_and_sizes_need_no_gpu():
     from rmnet_amd import _lib
     lib = _lib.load()
-    assert lib.rmnet_abi_version() == 4
+    assert lib.rmnet_abi_version() == 5
     assert lib.rmnet_error_string(0) == b'ok'
     for code in (-1, -2, -3, -4):
         assert len(lib.rmnet_error_string(code)) > 4
@@ -85,7 +85,7 @@ def test_flag_constants_of_the_python_mirror_match_the_header():
     from rmnet_amd.rmnet import MemoryReader, RMNet
     src = open(os.path.join(ROOT, 'include', 'rmnet_hip.h')).read()
     defs = {m.group(1): int(m.group(2)) for m in re.finditer(r'^#define\s+(RMNET_\w+)\s+(-?\d+)\b', src, re.M)}
-    assert defs['RMNET_ABI_VERSION'] == _lib.ABI_VERSION == 4
+    assert defs['RMNET_ABI_VERSION'] == _lib.ABI_VERSION == 5
     assert defs['RMNET_MR_FORCE_GENERIC'] == ops.MR_FORCE_GENERIC and defs['RMNET_MR_EXACT_FP32'] == ops.MR_EXACT_FP32
     assert defs['RMNET_MR_F16'] == ops.MR_F16 == defs['RMNET_BANK_F16'] == ops.BANK_F16
     assert len({defs['RMNET_MR_FORCE_GENERIC'], defs['RMNET_MR_EXACT_FP32'], defs['RMNET_MR_F16']}) == 3   # distinct bits
