@@ -129,6 +129,10 @@ int rmnet_boxes_to_cell_rects_i32(const int32_t *bboxes, int n_boxes, int k_per_
                                   * weight error of RMNET_MR_F16, which is what costs mask IoU on multi-object clips, is gone.  About the
                                   * speed of RMNET_MR_F16.  Mutually exclusive with it. */
 #define RMNET_BANK_MIXED 8       /* the same switch for rmnet_bank_read_f32_at */
+#define RMNET_MR_QX 16           /* fast shape only: RMNET_MR_F16 with an EXACT QUERY -- q enters the logits as a hi/lo pair (two MFMA terms), K, P
+                                  * and V stay rounded to fp16.  q's rounding is the one logit error that is coherent over all memory cells of
+                                  * a query; removing it recovers most of what RMNET_MR_F16 costs in mask IoU, at ~10 % of its speed. */
+#define RMNET_BANK_QX 16         /* the same switch for rmnet_bank_read_f32_at */
 
 size_t rmnet_memory_read_workspace_bytes(int no, int De, int Do, int T, int h, int w, int flags);
 int rmnet_memory_read_f32(const float *m_key, const float *m_val, const float *q_key,

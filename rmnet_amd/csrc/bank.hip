@@ -827,7 +827,7 @@ struct L2Prefetch {
   template <int kMode>
   __device__ inline void touch(int step, int w, int nw, int lane) {
     if (nparts <= 0) return;
-    if constexpr (kMode == 1) {
+    if constexpr (kMode != 2) {
       const int ja = jt0 + 2 * step;
       if (ja >= jt0 + ntl) return;                                         // (wave-uniform)
       const int la = c.seek(ja);
@@ -885,6 +885,10 @@ struct L2Prefetch {
 // then one per step.
 // ================================================================================================================
 // kMode 1 = the fp16-operand mode as described above.
+// kMode 3 = fp16 operands with an EXACT QUERY (RMNET_BANK_QX): kMode 1 plus the lo plane of q against the same K fragments (16 more
+// MFMAs per step, producers only).  The rounding of q is the one logit error that is COHERENT over all memory cells of a query
+// (K's roundings are independent from cell to cell and average out in the weighted sum): emulated on the CPU path it is most of
+// what the fp16-operand read costs in mask IoU on multi-object clips (profiles/r05_iou_emulation.md).
 // kMode 2 = the MIXED mode (RMNET_BANK_MIXED): the same pipeline with a step of ONE tile whose two ring planes are the hi and the
 // lo plane of its keys -- the logits S = K^T q are computed in the split mode's three terms (hi*hi + hi*lo + lo*hi: fp32-class,
 // 24 MFMAs per tile in two accumulator chains), the soft-max weights and the values enter the O = V P MFMAs rounded to fp16
@@ -899,9 +903,9 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
   const int o = wk.o;
   const int l15 = lane & 15, g = lane >> 4;
   const int jt0 = wk.jt0, ntl = wk.ntl;
-  constexpr int kTPS = kMode == 1 ? 2 : 1;           // tiles per step
-  constexpr int kNC = kMode == 1 ? 4 : 2;            // accumulator chains of S per step (16 cells each)
-  constexpr int kPf = kMode == 1 ? BK_PF : 2 * BK_PF;   // L2 prefetch distance in steps
+  constexpr int kTPS = kMode != 2 ? 2 : 1;           // tiles per step
+  constexpr int kNC = kMode != 2 ? 4 : 2;            // accumulator chains of S per step (16 cells each)
+  constexpr int kPf = kMode != 2 ? BK_PF : 2 * BK_PF;   // L2 prefetch distance in steps
   const int nst = (ntl + kTPS - 1) / kTPS;           // steps (fp16 mode: the last one may be half empty)
 #if BK_TRACE
   long long* trc = reinterpret_cast<long long*>(a.ws_o + (size_t)a.trace_slot * (size_t)kDo * kQT);
@@ -910,7 +914,7 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
   if (trace_on) trc[trn++] = t_entry;
 #endif
   BK_STAMP();
-  half8 qh[4], ql[kMode == 2 ? 4 : 1];
+  half8 qh[4], ql[kMode != 1 ? 4 : 1];
   {
     const int qn = wk.qt * kQT + wave * 16 + l15;
     const bool qvalid = qn < wk.Mq;
@@ -926,7 +930,7 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float x = qb[(size_t)(32 * ks + 8 * g + e) * b.hw] * keep;   // (range: query_range_check)
-        if constexpr (kMode == 2) {
+        if constexpr (kMode != 1) {
           _Float16 hi, lo;
           split_f16(x, hi, lo);
           qh[ks][e] = hi; ql[ks][e] = lo;
@@ -958,9 +962,18 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
   };
   struct S4 { f32x4 s[kNC]; };
   auto s_mfma = [&](const Frags& f, S4& r) {
-    if constexpr (kMode == 1) {                      // four independent chains, interleaved
+    if constexpr (kMode != 2) {                      // four independent chains, interleaved
 #pragma unroll
       for (int c = 0; c < 4; ++c) r.s[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (kMode == 3) {                    // exact query: the lo plane of q against the same K fragments, small terms first
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          r.s[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a0[ks], ql[ks], r.s[0], 0, 0, 0);
+          r.s[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a1[ks], ql[ks], r.s[1], 0, 0, 0);
+          r.s[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.b0[ks], ql[ks], r.s[2], 0, 0, 0);
+          r.s[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.b1[ks], ql[ks], r.s[3], 0, 0, 0);
+        }
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         r.s[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a0[ks], qh[ks], r.s[0], 0, 0, 0);
@@ -993,7 +1006,7 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
       for (int i = 0; i < 4; ++i) {
         r.s[0][i] = (4 * g + i < nva) ? r.s[0][i] : -INFINITY;
         r.s[1][i] = (16 + 4 * g + i < nva) ? r.s[1][i] : -INFINITY;
-        if constexpr (kMode == 1) {
+        if constexpr (kMode != 2) {
           r.s[2][i] = (4 * g + i < nvb) ? r.s[2][i] : -INFINITY;
           r.s[3][i] = (16 + 4 * g + i < nvb) ? r.s[3][i] : -INFINITY;
         }
@@ -1020,7 +1033,7 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
       const half2 ha = {(_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sv[2 * i], kSraw, nm)),
                         (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sv[2 * i + 1], kSraw, nm))};
       pa[i] = __builtin_bit_cast(unsigned, ha);
-      if constexpr (kMode == 1) {
+      if constexpr (kMode != 2) {
         const half2 hb = {(_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sv[8 + 2 * i], kSraw, nm)),
                           (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sv[8 + 2 * i + 1], kSraw, nm))};
         pb_[i] = __builtin_bit_cast(unsigned, hb);
@@ -1028,12 +1041,12 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
     }
     char* pb = Pl_ + pbuf * kPbuf + wave * 2048 + lane * 16;
     *reinterpret_cast<u32x4*>(pb) = pa;
-    if constexpr (kMode == 1) *reinterpret_cast<u32x4*>(pb + 1024) = pb_;
+    if constexpr (kMode != 2) *reinterpret_cast<u32x4*>(pb + 1024) = pb_;
     if (g == 0) Al[pbuf * kQT + l15 * 4 + wave] = alpha;
     // denominator: every row of ones x P is the column sum of the rounded weights of query l15
     f32x4 lc = {lsum * alpha, 0.f, 0.f, 0.f};
     lc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, __builtin_bit_cast(half8, pa), lc, 0, 0, 0);
-    if constexpr (kMode == 1) lc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, __builtin_bit_cast(half8, pb_), lc, 0, 0, 0);
+    if constexpr (kMode != 2) lc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, __builtin_bit_cast(half8, pb_), lc, 0, 0, 0);
     lsum = lc[0];
   };
   Cursor cs;                       // walks ahead of the soft-max: the cell counts of a step are fetched an iteration early
@@ -1042,7 +1055,7 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
     const int ja = jt0 + kTPS * step;
     const int la = cs.seek(ja);
     nva = ja < jt0 + ntl ? tarea[cs.tt] - la * kJT : 0;
-    if constexpr (kMode == 1) {
+    if constexpr (kMode != 2) {
       const int lb = cs.seek(ja + 1);
       nvb = ja + 1 < jt0 + ntl ? tarea[cs.tt] - lb * kJT : 0;
     } else {
@@ -1091,7 +1104,7 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
     // for the pipe behind the consumers' (~40 cycles each, trace) while its VALU chain sits behind them in program order
 #if BK_F16_INTERLEAVE
 #pragma unroll
-    for (int i = 0; i < (kMode == 1 ? 16 : 24); ++i) {
+    for (int i = 0; i < (kMode == 1 ? 16 : kMode == 3 ? 32 : 24); ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, kMode == 1 ? BK_F16_INTERLEAVE : (BK_F16_INTERLEAVE + 1) / 2, 0);
     }
@@ -1124,8 +1137,8 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
   const int o = wk.o;
   const int l15 = lane & 15;
   const int jt0 = wk.jt0, ntl = wk.ntl;
-  constexpr int kTPS = kMode == 1 ? 2 : 1;           // tiles per step (producer_loop_f16)
-  constexpr int kPf = kMode == 1 ? BK_PF : 2 * BK_PF;
+  constexpr int kTPS = kMode != 2 ? 2 : 1;           // tiles per step (producer_loop_f16)
+  constexpr int kPf = kMode != 2 ? BK_PF : 2 * BK_PF;
   const int nst = (ntl + kTPS - 1) / kTPS;
 #if BK_TRACE
   long long* trc = reinterpret_cast<long long*>(a.ws_o + (size_t)a.trace_slot * (size_t)kDo * kQT) + 1024;
@@ -1152,7 +1165,7 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
     const int la = ck.seek(jt0 + kTPS * step);
     const size_t offa = ((so0 + ck.tt) * b.hwp + (size_t)la * kJT) * kDe * sizeof(_Float16) + (size_t)ct * 16;
     kr[0] = *reinterpret_cast<const half8*>(b.kh + offa);
-    if constexpr (kMode == 1) {
+    if constexpr (kMode != 2) {
       const int lb = ck.seek(jt0 + 2 * step + 1);
       kr[1] = *reinterpret_cast<const half8*>(b.kh + ((so0 + ck.tt) * b.hwp + (size_t)lb * kJT) * kDe * sizeof(_Float16) + (size_t)ct * 16);
     } else {
@@ -1177,7 +1190,7 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
     k_store(k2, 2);
     k_store(k3, 3);
   }
-  half8 va[kCDT], vb[kMode == 1 ? kCDT : 1];   // V fragments of the step's tile(s)
+  half8 va[kCDT], vb[kMode != 2 ? kCDT : 1];   // V fragments of the step's tile(s)
   Cursor cv;
   cv.init(tpre, wk.t, jt0 + ntl - 1);
   {
@@ -1185,7 +1198,7 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
     const size_t offa = v_tile(cv.tt, la);
 #pragma unroll
     for (int dt = 0; dt < kCDT; ++dt) va[dt] = *reinterpret_cast<const half8*>(b.vh + offa + dt * 1024);
-    if constexpr (kMode == 1) {
+    if constexpr (kMode != 2) {
       const int lb = cv.seek(jt0 + 1);
       const size_t offb = v_tile(cv.tt, lb);
 #pragma unroll
@@ -1196,7 +1209,7 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
   for (int dt = 0; dt < kCDT; ++dt)
 #pragma unroll
     for (int it = 0; it < 4; ++it) acc[dt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
-  half8 pa[4], pb[kMode == 1 ? 4 : 1];   // P fragments of the current step
+  half8 pa[4], pb[kMode != 2 ? 4 : 1];   // P fragments of the current step
   f32x4 al;                        // its rescale factors
   auto p_frags = [&](int buf) {
     const char* pfr = Pl_ + buf * kPbuf;
@@ -1204,7 +1217,7 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       pa[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + lane * 16);
-      if constexpr (kMode == 1) pb[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + 1024 + lane * 16);
+      if constexpr (kMode != 2) pb[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + 1024 + lane * 16);
     }
   };
   __syncthreads();                                   // A: K steps 0..3 in the ring
@@ -1226,7 +1239,7 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
   auto v_next = [&](int step) {
     const int la = cv.seek(jt0 + kTPS * step);       // (clamped past the end)
     nva = b.vh + v_tile(cv.tt, la);
-    if constexpr (kMode == 1) {
+    if constexpr (kMode != 2) {
       const int lb = cv.seek(jt0 + 2 * step + 1);
       nvb = b.vh + v_tile(cv.tt, lb);
     }
@@ -1251,7 +1264,7 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
 #pragma unroll
       for (int it = 0; it < 4; ++it)
         acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va[dt], pa[it], acc[dt][it], 0, 0, 0);
-      if constexpr (kMode == 1) {
+      if constexpr (kMode != 2) {
 #pragma unroll
         for (int it = 0; it < 4; ++it)
           acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[dt], pb[it], acc[dt][it], 0, 0, 0);
@@ -1259,7 +1272,7 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
 #endif
 #if !(BK_ABLATE & 1)
       va[dt] = *reinterpret_cast<const half8*>(nva + dt * 1024);
-      if constexpr (kMode == 1) vb[dt] = *reinterpret_cast<const half8*>(nvb + dt * 1024);
+      if constexpr (kMode != 2) vb[dt] = *reinterpret_cast<const half8*>(nvb + dt * 1024);
 #endif
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1431,7 +1444,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     int target = a.target;
     if (!(BK_ABLATE & 256)) {
       const float static_bytes = (float)ng * (float)hw * (float)kDo * 4.0f * 2.5f;
-      const float compute_us = kLaunchUs + (kTerms == 1 ? kTileUsF16 : kTerms == 2 ? kTileUsMixed : kTileUs) * (float)W / (float)a.target;
+      const float compute_us = kLaunchUs + (kTerms == 1 || kTerms == 4 ? kTileUsF16 : kTerms == 2 ? kTileUsMixed : kTileUs) * (float)W / (float)a.target;
       int aside = (int)(static_bytes / (compute_us * (kTerms != 3 ? kStaticBytesPerUsF16 : kStaticBytesPerUs)) + 0.5f);
       aside = min(aside, a.target / 4);
       target = a.target - aside;
@@ -1441,7 +1454,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     // overlap): this search sits on the critical path of every workgroup, and one candidate at a time with shuffle
     // reductions cost 0.45 us per step, 3 us at the bench launch (r04 time line).
     constexpr int kSC = seg_cost_of(kTerms);
-    constexpr int kCq = kTerms == 1 ? 2 : 1;              // (fp16 mode: a step is two tiles, an odd chunk wastes half of one)
+    constexpr int kCq = kTerms == 1 || kTerms == 4 ? 2 : 1;   // (fp16 modes: a step is two tiles, an odd chunk wastes half of one)
     auto next_c = [](int c) { return c + (1 + (c >> 5) + kCq - 1) / kCq * kCq; };
     // chunks of this lane's object at chunk length c = bank_chunks(nqt, njt, c, kSC).nch with the two integer divisions done in
     // fp32 (all operands < 2^22: the quotient is off by at most one, fixed up) -- ~15 instructions instead of ~80
@@ -1563,11 +1576,12 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
 #if BK_CLK
     if (tid == 0 && clk_rec[5] == 0) clk_rec[5] = (long long)__builtin_amdgcn_s_memrealtime() - t_real;   // first segment starts
 #endif
-    if constexpr (kTerms != 3) {          // 1: fp16 operands, 2: mixed (S in three terms, PV in one) -- the same pipeline
+    if constexpr (kTerms != 3) {          // 1: fp16 operands, 4: the same with an exact query, 2: mixed (S in three terms, PV in one) -- one pipeline
+      constexpr int kMode = kTerms == 4 ? 3 : kTerms;
       if (producer)
-        producer_loop_f16<kTerms>(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, ln, t_entry, m_seg, l_seg);
+        producer_loop_f16<kMode>(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, ln, t_entry, m_seg, l_seg);
       else
-        consumer_loop_f16<kTerms>(a, wk, Kl_, Pl_, Al, tpre, wave, ln, t_entry, acc);
+        consumer_loop_f16<kMode>(a, wk, Kl_, Pl_, Al, tpre, wave, ln, t_entry, acc);
     } else {
       if (producer)
         producer_loop(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, ln, t_entry, m_seg, l_seg);
@@ -2205,6 +2219,8 @@ int launch_bank_main(const BankReadArgs& m, hipStream_t st) {
       hipLaunchKernelGGL(bk_main<1>, dim3(a.target), dim3(kRThreads), 0, st, a);
     else if (m.f16 == 2)
       hipLaunchKernelGGL(bk_main<2>, dim3(a.target), dim3(kRThreads), 0, st, a);
+    else if (m.f16 == 4)
+      hipLaunchKernelGGL(bk_main<4>, dim3(a.target), dim3(kRThreads), 0, st, a);
     else
       hipLaunchKernelGGL(bk_main<3>, dim3(a.target), dim3(kRThreads), 0, st, a);
     if (int e = check_launch()) return e;

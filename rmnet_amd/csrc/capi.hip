@@ -132,9 +132,9 @@ int rmnet_bank_read_f32_at(void* bank, int no, int Tcap, int h, int w, int T, co
                            void* workspace, size_t workspace_bytes, void* stream, void* ev_start, void* ev_mid,
                            void* ev_end) {
   BankReadArgs a;
-  if ((flags & ~(RMNET_BANK_F16 | RMNET_BANK_MIXED)) || flags == (RMNET_BANK_F16 | RMNET_BANK_MIXED)) return RMNET_E_INVALID_ARG;
+  if (flags != 0 && flags != RMNET_BANK_F16 && flags != RMNET_BANK_MIXED && flags != RMNET_BANK_QX) return RMNET_E_INVALID_ARG;
   a.bank = bank; a.no = no; a.Tcap = Tcap; a.h = h; a.w = w; a.T = T; a.T_dev = T_dev;
-  a.f16 = (flags & RMNET_BANK_F16) ? 1 : (flags & RMNET_BANK_MIXED) ? 2 : 0;
+  a.f16 = (flags & RMNET_BANK_F16) ? 1 : (flags & RMNET_BANK_MIXED) ? 2 : (flags & RMNET_BANK_QX) ? 4 : 0;
   a.qk = q_key; a.qv = q_val; a.qry_rects = qry_rects; a.out = mem_val;
   a.ws_o = nullptr; a.ws_ml = nullptr; a.ws_plan = nullptr; a.slots = 0;
   a.ws = workspace; a.ws_bytes = workspace_bytes;

@@ -220,8 +220,9 @@ constexpr int kSegCostF16 = RMNET_SEG_COST_F16;
 #define RMNET_SEG_COST_MIXED 12   // mixed mode (S in three terms, PV in one): a tile costs about what it costs in the fp16-operand mode
 #endif
 constexpr int kSegCostMixed = RMNET_SEG_COST_MIXED;
-// kTerms = the arithmetic of a bank read: 3 = split fp16 (three MFMA terms everywhere), 1 = fp16 operands, 2 = mixed
-__host__ __device__ constexpr int seg_cost_of(int kTerms) { return kTerms == 1 ? kSegCostF16 : kTerms == 2 ? kSegCostMixed : kSegCost; }
+// kTerms = the arithmetic of a bank read: 3 = split fp16 (three MFMA terms everywhere), 1 = fp16 operands, 4 = fp16 operands with an exact
+// query (two terms for the logits), 2 = mixed (three terms for the logits, one for O = V P)
+__host__ __device__ constexpr int seg_cost_of(int kTerms) { return kTerms == 1 || kTerms == 4 ? kSegCostF16 : kTerms == 2 ? kSegCostMixed : kSegCost; }
 // Division of the launch plan's small non-negative integers (all < 2^22).  On the device hipcc expands an integer division by a
 // run-time divisor into ~35 instructions, and the plan + the chunk lookup of bk_main do a dozen of them on the critical path of
 // every workgroup; an fp32 reciprocal is off by at most one there, and the remainder fixes it up (exact, ~8 instructions).
@@ -288,7 +289,7 @@ struct BankReadArgs {
   int gate = 0;               // != 0: bk_main returns at once when the bank's overflow word is set
   const int32_t* T_dev = nullptr;   // optional device-resident frame counter added to T
   int f16 = 0;                // arithmetic: 0 split fp16 (three MFMA terms), 1 fp16 operands (hi planes only, one term), 2 mixed
-                              // (the logits S in three terms, O = V P in one: RMNET_BANK_MIXED)
+                              // (the logits S in three terms, O = V P in one: RMNET_BANK_MIXED), 4 fp16 operands + exact query (RMNET_BANK_QX)
   int t0 = 0;                 // first slot read (chunked reads of a bank longer than one launch can take)
   float* ml_out = nullptr;    // optional [no][2][h*w]: soft-max state of the merged query cells (bank.hip: bk_chain)
 };

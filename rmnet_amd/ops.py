@@ -171,23 +171,26 @@ BANK_F16 = 4                      # include/rmnet_hip.h: RMNET_BANK_F16 (== RMNE
 MR_F16 = 4
 BANK_MIXED = 8                    # RMNET_BANK_MIXED (== RMNET_MR_MIXED)
 MR_MIXED = 8
-_PRECISION_FLAGS = {'split': 0, 'f16': BANK_F16, 'mixed': BANK_MIXED}
+BANK_QX = 16                      # RMNET_BANK_QX (== RMNET_MR_QX)
+MR_QX = 16
+_PRECISION_FLAGS = {'split': 0, 'f16': BANK_F16, 'mixed': BANK_MIXED, 'qx': BANK_QX}
 
 
 def _precision(p):
     """'split': K, V, q and P enter the MFMAs as fp16 hi/lo pairs, three terms, fp32-class accuracy (default).
     'mixed': the logits K^T q in those three terms, the soft-max weights and V rounded to fp16 for V P (one term).
-    'f16': hi planes only -- fp16 operands, fp32 accumulate, about 2^-11 relative (include/rmnet_hip.h)."""
+    'f16': hi planes only -- fp16 operands, fp32 accumulate, about 2^-11 relative (include/rmnet_hip.h).
+    'qx': 'f16' with the query as a hi/lo pair (its rounding is the logit error that does not average out)."""
     if p not in _PRECISION_FLAGS:
-        raise ValueError("precision must be 'split', 'mixed' or 'f16'")
+        raise ValueError("precision must be 'split', 'mixed', 'qx' or 'f16'")
     return p
 
 
 def _loop_precision(p):
     """Arithmetic of the frame loop's bank read: 'auto' (default), 'split', 'mixed' or 'f16' -- see RMNet.__init__ and
     profiles/r05_iou_calibration.md for what 'auto' picks and why."""
-    if p not in ('auto', 'split', 'mixed', 'f16'):
-        raise ValueError("read_precision must be 'auto', 'split', 'mixed' or 'f16'")
+    if p not in ('auto', 'split', 'mixed', 'qx', 'f16'):
+        raise ValueError("read_precision must be 'auto', 'split', 'mixed', 'qx' or 'f16'")
     return p
 
 

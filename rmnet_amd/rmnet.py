@@ -346,10 +346,13 @@ class RMNet(nn.Module):
         return out
 
     @torch.no_grad()
-    def forward(self, frames, masks, optical_flows, n_objects, memorize_every, device=None, _exact=False, graph=None):
+    def forward(self, frames, masks, optical_flows, n_objects, memorize_every, device=None, _exact=False, graph=None,
+                return_logits=False):
         """models/rmnet.py:385-452.  frames [B,N,3,H,W] f32, masks [B,N,K,H,W] (one-hot, any int or
         float dtype), optical_flows [B,N,2,H,W] f32, n_objects [B,N] int -> est_masks [B,N,K,H,W]
         f32 on the GPU (the reference returns them on the host unless several GPUs are visible).
+        ``return_logits=True`` returns ``(est_masks, logits)``: the [B,N,K,H,W] logits the masks are the soft-max of (after the
+        edits of models/rmnet.py:436-448; frame 0 is zeros) -- what the parity tests compare besides the probabilities.
 
         ``graph=True``: replay the frame step as ONE captured HIP graph instead of ~340 launches per frame.
         The first segmented frame always runs eagerly (it warms MIOpen up and runs the fused-warp self-check), the graph
@@ -368,6 +371,7 @@ class RMNet(nn.Module):
         K = masks.shape[2]
         est = torch.zeros(B, N, K, H, W, device=dev)
         est[:, 0] = masks_dev[:, 0]
+        logits = torch.zeros(B, N, K, H, W, device=dev) if return_logits else None   # (frame 0 has none: models/rmnet.py:397)
 
         # ---- clip-level bookkeeping, hoisted out of the frame loop (the only host syncs)
         n_obj_host = n_objects.cpu()
@@ -410,13 +414,16 @@ class RMNet(nn.Module):
                     logit[b, missing] = _ABSENT_LOGIT
                     prob = None
             est[:, t] = F.softmax(logit, dim=1) if prob is None else prob
+            if return_logits:
+                logits[:, t] = logit
         if bank.overflow_count():   # (one host sync per clip) K / V / q_key outside the split-fp16 window: redo the clip exactly
             if isinstance(bank, ops.MemoryBank) and bank.timeout_count():
                 import warnings
                 warnings.warn('rmnet_amd: %d merge(s) of the bank read timed out on this device (scheduling problem?); '
                               'the clip is re-read with the exact-fp32 kernels' % bank.timeout_count())
-            return self.forward(frames, masks, optical_flows, n_objects, memorize_every, device=dev, _exact=True)
-        return est
+            return self.forward(frames, masks, optical_flows, n_objects, memorize_every, device=dev, _exact=True,
+                                return_logits=return_logits)
+        return (est, logits) if return_logits else est
 
     def _capture_frame_step(self, ctx, bank, prev_frame, prev_mask, cur_frame, cur_flow):
         """Capture ``frame_step(commit=False)`` on static copies of its four inputs; returns ``replay(prev_frame,

@@ -1647,52 +1647,37 @@ _CALIB_CASES = {   # objects, H, W, memorize_every, seed, blob size, frames
 }   # (the 720p 3-object clip and the 30-frame runs are in profiles/r04_iou_calibration.md: tools/iou_calib.py; not re-run by the suite)
 
 
-@pytest.mark.parametrize('case', sorted(_CALIB_CASES))
-def test_iou_bar_against_the_cpu_path_on_long_clips(case, oracle_mod):
+_CALIB_PARAMS = [pytest.param(c, m, marks=pytest.mark.xfail(strict=True, reason='documented miss: the fp16-operand read loses 1.1e-3 of '
+                                                           'IoU on this 5-object clip (profiles/r04_iou_calibration.md); auto does not use it there'))
+                 if (c, m) == ('5obj-480p', 'f16') else pytest.param(c, m)
+                 for c in sorted(_CALIB_CASES) for m in ('auto', 'exact', 'mixed', 'f16')]
+
+
+@pytest.mark.parametrize('case,mode', _CALIB_PARAMS)
+def test_iou_bar_against_the_cpu_path_on_long_clips(case, mode, oracle_mod):
     """The north star's bar -- mask IoU within 1e-3 of the CPU path -- measured against THAT path (OracleRMNet on the host
-    cores) on 20-frame clips with 3 / 5 objects (12 frames with one) at 480x854, for the GPU loop in its default
-    configuration ('auto': fp16-operand read for one object per clip, split-fp16 for several), with the exact-fp32 read and
-    with the fp16-operand read forced.  Bars: default and exact >= 0.999 per object on every clip; fp16 forced >= 0.999 with
-    one object (probabilities within 1e-3 as well) and >= 0.998 otherwise (measured 0.9986-0.9995 on these procedural random
-    weights: that margin is why 'auto' does not use it there; profiles/r04_iou_calibration.md has the table of the 30-frame
-    and other-size runs, tools/iou_calib.py makes it)."""
+    cores) on 20-frame clips with 3 / 5 objects (12 frames with one) at 480x854, for the GPU loop in its default configuration
+    ('auto'), with the exact-fp32 read, with the mixed arithmetic and with the fp16-operand read forced.  ONE bar for all:
+    >= 0.999 per object.  The fp16-operand read misses it on the 5-object clip (0.9989: strict xfail, a documented miss --
+    'auto' does not use that arithmetic for several objects); profiles/r05_iou_calibration.md has the full table
+    (tools/iou_calib.py makes it).  NOTE: the one-object clip here is SATURATED (its mask is the whole frame): it checks the
+    plumbing of a long clip, not the read -- the one-object bar that can fail is test_live_boundary_clips_meet_the_bar_in_every_arithmetic."""
     from rmnet_amd.synthetic import synthetic_clip
     n_obj, H, W, every, seed, size, N = _CALIB_CASES[case]
-    prod, ref = _nets(oracle_mod)
+    prod, ref = _nets(oracle_mod, 'auto' if mode == 'exact' else mode)
     prod.fuse_epilogues()
-    assert prod.read_precision == 'auto'
     frames, masks, flows, n_objects = synthetic_clip(N, n_obj + 1, H, W, seed=seed, size=size)
-    threads = torch.get_num_threads()
-    torch.set_num_threads(min(16, threads))           # (the CPU path is fastest at 16 threads on the GPU box: bench.py cpu_baseline.sweep)
-    oracle_mod.set_num_threads(min(16, threads))
-    try:
-        with torch.no_grad():
-            est_cpu = ref(frames, masks, flows, n_objects, every)
-    finally:
-        torch.set_num_threads(threads)
-        oracle_mod.set_num_threads(threads)
+    est_cpu, _ = _cpu_path(oracle_mod, ref, 'calib-' + case, frames, masks, flows, n_objects, every)
     lab_cpu = est_cpu.argmax(2).numpy()
-
-    def run(precision, exact=False):
-        prod.read_precision = precision
-        with torch.no_grad():
-            est = prod(frames, masks, flows, n_objects, every, _exact=exact).cpu()
-        lab = est.argmax(2).numpy()
-        return min(oracle_mod.iou(lab[:, 1:] == k, lab_cpu[:, 1:] == k) for k in range(1, n_obj + 1)), est
-    iou_auto, _ = run('auto')
-    iou_exact, _ = run('auto', exact=True)
-    iou_f16, est_f16 = run('f16')
-    prod.read_precision = 'auto'
-    assert prod.resolve_read_precision([n_obj]) == ('f16' if n_obj == 1 else 'split')
-    assert iou_exact >= 0.999 and iou_auto >= 0.999, (case, iou_exact, iou_auto, iou_f16)
-    if n_obj == 1:
-        assert iou_f16 >= 0.999 and float((est_f16 - est_cpu).abs().max()) < 1e-3, (case, iou_f16)
-    else:
-        assert iou_f16 >= 0.998, (case, iou_f16)
+    with torch.no_grad():
+        est = prod(frames, masks, flows, n_objects, every, _exact=(mode == 'exact')).cpu()
+    lab = est.argmax(2).numpy()
+    iou = min(oracle_mod.iou(lab[:, 1:] == k, lab_cpu[:, 1:] == k) for k in range(1, n_obj + 1))
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
     if os.path.isdir(out):
         with open(os.path.join(out, 'iou_bar_test_table.txt'), 'a') as fh:
-            fh.write('%s: default(auto) %.5f exact %.5f f16 %.5f\n' % (case, iou_auto, iou_exact, iou_f16))
+            fh.write('%s %s (auto -> %s): %.5f\n' % (case, mode, prod.resolve_read_precision([n_obj]), iou))
+    assert iou >= 0.999, (case, mode, iou)
 
 
 def test_f16_mode_through_strides_partial_reads_and_graph_replay(oracle_mod):
@@ -1841,3 +1826,213 @@ def test_whole_loop_grows_the_memory_to_five_frames(precision, oracle_mod):
     assert float((est - est_cpu).abs().max()) < 1e-3
     lab, lab_cpu = est.argmax(2).numpy(), est_cpu.argmax(2).numpy()
     assert oracle_mod.iou(lab[:, 1:] == 1, lab_cpu[:, 1:] == 1) >= 0.999
+
+
+# ----------------------------------------------------------------------------- round 5: parity that can fail
+# (tests/live_fixture.py: one-object clips whose estimated masks have live boundaries; the mixed arithmetic)
+import live_fixture as lf   # noqa: E402  (tests/ is on sys.path under pytest's rootdir conftest)
+
+_CPU_PATH_CACHE = {}
+
+
+def _cpu_path(oracle_mod, ref, key, frames, masks, flows, n_objects, every):
+    """The CPU path's (probabilities, logits) of a clip, once per session (several tests / parameters compare against it)."""
+    if key not in _CPU_PATH_CACHE:
+        threads = torch.get_num_threads()
+        torch.set_num_threads(min(16, threads))       # (fastest count on the GPU box: bench.py cpu_baseline.sweep)
+        oracle_mod.set_num_threads(min(16, threads))
+        try:
+            with torch.no_grad():
+                _CPU_PATH_CACHE[key] = ref(frames, masks, flows, n_objects, every, return_logits=True)
+        finally:
+            torch.set_num_threads(threads)
+            oracle_mod.set_num_threads(threads)
+    return _CPU_PATH_CACHE[key]
+
+
+def _table(line):
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(out):
+        with open(os.path.join(out, 'live_iou_table.txt'), 'a') as fh:
+            fh.write(line + '\n')
+
+
+# Bar on the foreground LOGIT of a live pixel (|logit| < 10 on both sides), GPU loop vs CPU path.  Where it comes from: a label
+# flips when the logit error exceeds the pixel's distance from 0; on these fixtures 1-2 % of the pixels lie within 0.4 logit units
+# of the threshold around a foreground of ~20 % of the frame, so an IoU loss of 1e-3 corresponds to a uniform logit error of about
+# 2e-2.  Measured (profiles/r05_iou_calibration.md): exact-fp32 GPU loop vs CPU path <= 2e-3 (MIOpen vs CPU convolutions), the
+# arithmetic modes <= 6e-3.
+LIVE_LOGIT_BAR = 2e-2
+
+
+@pytest.mark.parametrize('mode', ['auto', 'exact', 'split', 'mixed', 'qx', 'f16'])
+@pytest.mark.parametrize('name', ['live480-a', 'live480-b', 'live480-c'])
+def test_live_boundary_clips_meet_the_bar_in_every_arithmetic(name, mode, oracle_mod):
+    """The north star's bar -- mask IoU within 1e-3 of the CPU path -- on one-object 480x854 clips whose masks HAVE a boundary
+    (cover 10-60 %, >= 1 % of the pixels within 0.1 of the threshold on every frame: asserted), for the GPU loop with the
+    exact-fp32 read, the three bank arithmetics and the default.  Also compared: the logits (LIVE_LOGIT_BAR) and the
+    probabilities.  That this comparison CAN fail is test_mutated_memory_read_fails_the_parity_metric."""
+    prod, ref = _nets(oracle_mod, 'auto' if mode == 'exact' else mode)
+    frames, masks, flows, n_objects, every, delta = lf.make_clip(name)
+    lf.shift_foreground_bias(prod, delta)
+    lf.shift_foreground_bias(ref, delta)
+    prod.fuse_epilogues()
+    est_cpu, log_cpu = _cpu_path(oracle_mod, ref, name, frames, masks, flows, n_objects, every)
+    lf.assert_live(est_cpu, name)
+    with torch.no_grad():
+        est, logits = prod(frames, masks, flows, n_objects, every, _exact=(mode == 'exact'), return_logits=True)
+    est, logits = est.cpu(), logits.cpu()
+    iou, gap, dp = lf.label_iou(est, est_cpu), lf.logit_gap(logits, log_cpu), float((est - est_cpu).abs().max())
+    _table('%s %-5s (auto -> %s): IoU %.5f  max live fg-logit diff %.2e  max prob diff %.2e  cover/near %s' % (
+        name, mode, prod.resolve_read_precision([1]), iou, gap, dp, ' '.join('%.3f/%.3f' % cn for cn in lf.liveness(est_cpu))))
+    assert iou >= 0.999, (name, mode, iou)
+    assert gap <= LIVE_LOGIT_BAR, (name, mode, gap)
+    assert dp <= LIVE_LOGIT_BAR / 4 * 1.5, (name, mode, dp)      # (d p = p (1 - p) d logit <= d logit / 4; x1.5: clamped pixels)
+
+
+@pytest.mark.parametrize('mutation', ['zero', 'noise-1pct'])
+def test_mutated_memory_read_fails_the_parity_metric(mutation, oracle_mod, monkeypatch):
+    """Mutation check of the parity metric: the SAME comparison as above (GPU loop vs CPU path on a live-boundary clip,
+    label IoU >= 0.999) with the memory half of every read-out of the GPU loop zeroed / noised by 1 % of its standard
+    deviation must FAIL -- and with the read-out left alone it passes.  (On the saturated clips of rounds 1-4 the zeroed
+    read-out left the IoU at 0.99985: those assertions could not see the read.)"""
+    from rmnet_amd import ops
+    name = 'live480-b'      # (the fixture with the softest boundary: CPU emulation of the 1 % noise gives IoU 0.9970)
+    prod, ref = _nets(oracle_mod, 'split')
+    frames, masks, flows, n_objects, every, delta = lf.make_clip(name)
+    lf.shift_foreground_bias(prod, delta)
+    lf.shift_foreground_bias(ref, delta)
+    prod.fuse_epilogues()
+    est_cpu, _ = _cpu_path(oracle_mod, ref, name, frames, masks, flows, n_objects, every)
+    with torch.no_grad():
+        clean = prod(frames, masks, flows, n_objects, every).cpu()
+    assert lf.label_iou(clean, est_cpu) >= 0.999
+    orig = ops.MemoryBank.read_staged
+    gen = torch.Generator(device=dev()).manual_seed(5)
+
+    def mutated(self, *a, **k):
+        out = orig(self, *a, **k)
+        mem = out[:, :512]
+        if mutation == 'zero':
+            mem.zero_()
+        else:
+            mem += 0.01 * mem.std() * torch.randn(mem.shape, generator=gen, device=mem.device)
+        return out
+    monkeypatch.setattr(ops.MemoryBank, 'read_staged', mutated)
+    with torch.no_grad():
+        bad = prod(frames, masks, flows, n_objects, every).cpu()
+    iou = lf.label_iou(bad, est_cpu)
+    _table('%s mutation %s: IoU %.5f' % (name, mutation, iou))
+    assert iou < 0.999, (mutation, iou)
+    if mutation == 'zero':
+        assert iou < 0.9, iou
+
+
+@pytest.mark.parametrize('no,T,h,w,regional', [
+    (1, 1, 4, 5, False), (2, 3, 9, 13, True), (1, 5, 30, 54, True), (1, 7, 16, 24, False), (2, 9, 10, 7, True),
+    (14, 2, 6, 9, True), (70, 1, 4, 5, True), (5, 3, 30, 54, True), (5, 5, 30, 54, True), (3, 20, 12, 20, True),
+    (1, 70, 5, 6, True), (50, 2, 12, 20, False), (24, 3, 12, 20, True)])
+@pytest.mark.parametrize('mode', ['mixed', 'qx'])
+def test_bank_read_mixed_mode_vs_oracle(mode, no, T, h, w, regional, oracle_mod):
+    """The mixed arithmetic (RMNET_BANK_MIXED: logits in three split-fp16 terms, O = V P in one) and the fp16-operand arithmetic
+    with an exact query (RMNET_BANK_QX) on the cases of test_bank_read_vs_oracle.  The mixed mode's bar is the rounding of P and V
+    alone: |error| <= 2^-10 max|v| whatever the logits are (no widening with the logit range, unlike the fp16-operand modes)."""
+    from rmnet_amd import ops
+    rng = np.random.RandomState(no * 1000 + T * 100 + h + 1)
+    mk, mv, qk, qv, mr, qr = _random_case(rng, no, T, h, w, regional=regional)
+    bank = ops.MemoryBank(no, T + 2, h, w, dev(), precision=mode)
+    for t in range(T):
+        bank.append(t, cu(mk[:, :, t]), cu(mv[:, :, t]), None if mr is None else cu(mr[:, t]))
+    if regional:
+        want, _ = oracle_mod.regional_memory_read(mk, mv, qk, qv, mr, qr)
+        got = bank.read(T, cu(qk), cu(qv), cu(qr)).cpu().numpy()
+    else:
+        want, _ = oracle_mod.memory_read(mk, mv, qk, qv)
+        got = bank.read(T, cu(qk), cu(qv)).cpu().numpy()
+    _f16_bars(got, want, float(np.abs(mv).max()))
+    assert bank.overflow_count() == 0
+
+
+def test_mixed_mode_keeps_the_logits_exact(golden_dir, oracle_mod):
+    """Where the two reduced arithmetics differ: a soft-max with logits in the tens.  The reference's golden 'peaky' vectors
+    (logits to 32) and a x9 spike (logit ~36) through the drop-in entry: the mixed mode meets the UN-widened bar (its weights
+    carry no |S| 2^-11 error), the fp16-operand mode needs the widened one.  Also: out-of-window values fall back to the exact kernel."""
+    from rmnet_amd import ops
+    g = np.load(os.path.join(golden_dir, 'memory_reader.npz'))
+    checked = 0
+    for name in sorted({k.split('.')[0] for k in g.files}):
+        if name + '.m_key' not in g.files or name + '.mem_val' not in g.files:
+            continue
+        mk, mv, qk, qv = (g[name + '.' + k].astype(np.float32) for k in ('m_key', 'm_val', 'q_key', 'q_val'))
+        if mk.shape[1] != 128 or mv.shape[1] != 512:
+            continue
+        got, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), flags=ops.MR_MIXED)
+        _f16_bars(got.cpu().numpy(), g[name + '.mem_val'].astype(np.float32), float(np.abs(mv).max()))
+        checked += 1
+    assert checked >= 1
+    rng = np.random.RandomState(5)
+    no, T, h, w = 2, 4, 8, 16
+    mk, mv, qk, qv, _, _ = _random_case(rng, no, T, h, w, regional=False)
+    mk[:, :, 3, h - 1, w - 2] = qk[:, :, 2, 3] * 9.0
+    want, _ = oracle_mod.memory_read(mk, mv, qk, qv)
+    got_m, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), flags=ops.MR_MIXED)
+    got_h, _ = ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), flags=ops.MR_F16)
+    em = np.abs(got_m.cpu().numpy()[:, :512] - want[:, :512])
+    eh = np.abs(got_h.cpu().numpy()[:, :512] - want[:, :512])
+    _f16_bars(got_m.cpu().numpy(), want, float(np.abs(mv).max()))
+    assert float(em.mean()) < float(eh.mean())
+    with pytest.raises(RuntimeError):
+        ops.memory_read(cu(mk), cu(mv), cu(qk), cu(qv), flags=ops.MR_MIXED | ops.MR_F16)
+    mv2 = mv.copy()
+    mv2[1, 7, 2, 3, 4] = 5000.0
+    want2, _ = oracle_mod.memory_read(mk, mv2, qk, qv)
+    got2, _ = ops.memory_read(cu(mk), cu(mv2), cu(qk), cu(qv), flags=ops.MR_MIXED)
+    np.testing.assert_allclose(got2.cpu().numpy(), want2, atol=MR_ATOL * 50, rtol=MR_RTOL)
+
+
+def test_graph_replay_is_refused_for_banks_longer_than_one_launch(oracle_mod, monkeypatch):
+    """Round-4 advisor: a bank of more than BANK_MAX_SLOTS frames is read in host-planned chunks, so its frame count would be
+    baked into a captured frame step.  forward(graph=True) must run such a clip eagerly (same masks as graph=False), and
+    read_staged must refuse to be captured.  (BANK_MAX_SLOTS is lowered to 3 for the test: the kernels' own limit stays 2048.)"""
+    from rmnet_amd import networks, ops
+    from rmnet_amd.rmnet import RMNet
+    from rmnet_amd.synthetic import synthetic_clip
+    monkeypatch.setattr(ops, 'BANK_MAX_SLOTS', 3)
+    net = networks.procedural_init_(RMNet(None)).to(dev()).eval()
+    net.fuse_epilogues()
+    frames, masks, flows, n_objects = synthetic_clip(8, 2, 96, 160, seed=3)
+    with torch.no_grad():
+        est_g = net(frames, masks, flows, n_objects, 1, graph=True).cpu()     # capacity 7 > 3: must not capture
+        est_e = net(frames, masks, flows, n_objects, 1, graph=False).cpu()
+    assert torch.equal(est_g, est_e)
+    bank = ops.MemoryBank(1, 8, 6, 10, dev())
+    k4, v4 = torch.randn(1, 128, 6, 10, device=dev()), torch.randn(1, 512, 6, 10, device=dev())
+    bank.stage(k4, v4, None)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        bank.read_staged(k4, v4)
+    torch.cuda.current_stream().wait_stream(side)
+    with pytest.raises(RuntimeError, match='chunked'):
+        with torch.cuda.graph(g):
+            bank.read_staged(k4, v4)
+    torch.cuda.synchronize()
+    assert ops.TensorBank(1, 2, 6, 10, dev()).timeout_count() == 0
+
+
+def test_bench_launches_its_own_ranks():
+    """``python bench.py --gpus 2`` from a plain shell (no torch.distributed.run around it, WORLD_SIZE unset): bench.py becomes the
+    launcher of its two ranks -- here over gloo, both on cuda:0 -- and rank 0's single JSON line comes back."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dist-backend', 'gloo', '--steps', '2',
+                          '--warmup', '1', '--clips-per-gpu', '1', '--no-cpu-baseline', '--no-extras', '--no-miopen-find'],
+                         capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['steps'] == 2 and line['multi_gpu']['backend'] == 'gloo' and line['value'] > 0

@@ -261,3 +261,50 @@ def test_sampled_memory_read_is_the_full_one(oracle_mod):
     full_r, _ = oracle_mod.regional_memory_read(mk, mv, qk, qv, mr, qr)
     got_r = oracle_mod.regional_memory_read_sampled(mk, mv, qk, mr, qr, qidx)
     assert np.array_equal(got_r, full_r[:, :512].reshape(no, 512, h * w)[:, :, qidx].transpose(0, 2, 1))
+
+
+# ----------------------------------------------------------------------------- round 5: a parity metric that can fail
+def _cpu_clip(oracle_mod, reader, frames, masks, flows, n_objects, every, delta):
+    import live_fixture as lf
+    from rmnet_amd import networks
+    net = lf.shift_foreground_bias(networks.procedural_init_(oracle_mod.OracleRMNet(reader=reader)).eval(), delta)
+    with torch.no_grad():
+        return net(frames, masks, flows, n_objects, every, return_logits=True)
+
+
+def test_saturated_clip_cannot_see_the_memory_read(oracle_mod):
+    """Why tests/live_fixture.py exists: on an ordinary synthetic one-object clip with the procedural weights the estimated mask
+    is the whole frame, and the label IoU against the CPU path stays >= 0.999 with the memory half of every read-out ZEROED.
+    (The round-4 verdict found this on the 480x854 clips of the GPU suite; here at 240x432, CPU only.)"""
+    import live_fixture as lf
+    from rmnet_amd.synthetic import synthetic_clip
+    frames, masks, flows, n_objects = synthetic_clip(4, 2, 240, 432, seed=11, size=2.1)
+    ref, _ = _cpu_clip(oracle_mod, 'torch', frames, masks, flows, n_objects, 1, 0.0)
+    bad, _ = _cpu_clip(oracle_mod, lf.rounded_reader('exact', mutate='zero'), frames, masks, flows, n_objects, 1, 0.0)
+    assert min(c for c, _ in lf.liveness(ref)) > 0.95          # the "object" covers the whole frame
+    assert lf.label_iou(bad, ref) >= 0.999                     # ... and the comparison does not notice a dead memory read
+
+
+def test_live_fixture_sees_mutations_and_prices_the_roundings(oracle_mod):
+    """The live-boundary fixture (decoder foreground bias shifted: tests/live_fixture.py) on the CPU: (1) its masks have a
+    boundary on every frame; (2) MUTATION CHECK -- with the read-out zeroed or noised by 1 % the parity metric (label IoU
+    >= 0.999 vs the unmutated path) FAILS, with 0.1 % noise it holds; (3) the roundings of the bank's reduced arithmetics
+    (fp16 operands; the same with an exact query; mixed), restated on the CPU, stay well inside it -- logits included."""
+    import live_fixture as lf
+    frames, masks, flows, n_objects, every, delta = lf.make_clip('live240')
+    ref, ref_l = _cpu_clip(oracle_mod, 'torch', frames, masks, flows, n_objects, every, delta)
+    lf.assert_live(ref, 'live240')
+    run = lambda reader: _cpu_clip(oracle_mod, reader, frames, masks, flows, n_objects, every, delta)
+    zero, _ = run(lf.rounded_reader('exact', mutate='zero'))
+    assert lf.label_iou(zero, ref) < 0.9
+    noisy, noisy_l = run(lf.rounded_reader('exact', mutate=('noise', 0.01)))
+    assert lf.label_iou(noisy, ref) < 0.999 and lf.logit_gap(noisy_l, ref_l) > 2e-2
+    quiet, _ = run(lf.rounded_reader('exact', mutate=('noise', 0.001)))
+    assert lf.label_iou(quiet, ref) >= 0.999
+    gaps = {}
+    for mode in ('f16', 'qx', 'mixed'):
+        est, lg = run(lf.rounded_reader(mode))
+        gaps[mode] = lf.logit_gap(lg, ref_l)
+        assert lf.label_iou(est, ref) >= 0.9995, mode
+        assert gaps[mode] < 5e-3, (mode, gaps[mode])
+    assert gaps['qx'] < gaps['f16'] and gaps['mixed'] < gaps['f16']     # q's rounding is the largest single contribution
