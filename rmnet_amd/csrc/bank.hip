@@ -362,6 +362,9 @@ constexpr int kRThreads = 64 * (kProducers + kConsumers);  // 768 = 12 waves = 3
 #ifndef BK_OUT_AUX
 #define BK_OUT_AUX 0   // cache policy of the stores to `out` (buffer aux bits: 2 = nt, 16 = sc1 write-through)
 #endif
+#ifndef BK_PLAN_NOEQ
+#define BK_PLAN_NOEQ 0 // experiments only: 1 = never take the equalised plan (A/B of the round-5 plan change)
+#endif
 #ifndef BK_CLK
 #define BK_CLK 0       // experiments only: per-workgroup shader-cycle / real-time stamps behind the plan records
 #endif
@@ -1482,12 +1485,22 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
       if (n3 <= target) { C0 = c3; break; }
       C0 = next_c(c3);
     }
-    const bool own = wave_sum_fast(bank_chunks(nqt, njt, C0, kSC, true).nch) <= target;   // short objects as blocks of their own (common.h)
-    const BankChunks bc0 = bank_chunks(nqt, njt, C0, kSC, own);
+    // EQUALISED column blocks (common.h: no remainder chunks, a pair has ceil(njt / C) partials) if they fit the workgroups at C0 or one
+    // of the next two candidates; else short objects as blocks of their own if that fits; else the plain plan.
+    int blocks = 0;
+    {
+      auto neq_at = [&](int c) { return nqt * (njt > 0 ? fdiv(njt + c - 1, c, __builtin_amdgcn_rcpf((float)c)) : 0); };
+      const int c1 = next_c(C0), c2 = next_c(c1);
+      const int m0 = wave_sum_fast(neq_at(C0)), m1 = wave_sum_fast(neq_at(c1)), m2 = wave_sum_fast(neq_at(c2));
+      const int ceq = m0 <= target ? C0 : m1 <= target ? c1 : (m2 <= target && kTerms != 3) ? c2 : 0;   // (split mode: a tile costs 3x, one candidate less)
+      if (ceq && !(BK_PLAN_NOEQ)) { C0 = ceq; blocks = 2; }
+    }
+    if (!blocks && wave_sum_fast(bank_chunks(nqt, njt, C0, kSC, 1).nch) <= target) blocks = 1;   // short objects as blocks of their own (common.h)
+    const BankChunks bc0 = bank_chunks(nqt, njt, C0, kSC, blocks);
     const int my_ch = bc0.nch, my_sl = bc0.nch + (bc0.R > 0 ? nqt : 0);   // chunks; slots (a remainder chunk can add one per query tile)
     const int nch = wave_scan_incl_fast(my_ch), nsl = wave_scan_incl_fast(my_sl);
     if (tid < ng) { o_cb[tid] = nch - my_ch; o_sb[tid] = nsl - my_sl; }
-    if (tid == RMNET_WAVE - 1) { plan_n = nch; plan_c = bc0.C; plan_own = own ? 1 : 0; }
+    if (tid == RMNET_WAVE - 1) { plan_n = nch; plan_c = bc0.C; plan_own = blocks; }
   }
   __syncthreads();
   auto sld = [](const int& x) { return __builtin_amdgcn_readfirstlane(x); };   // LDS value -> SGPR
@@ -1524,7 +1537,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   const int og = le ? 63 - __builtin_clzll(le) : 0;
   auto pick = [&](int v) { return __builtin_amdgcn_readlane(v, og); };
   const int nqt = pick(v_nqt), njt = pick(v_njt);
-  const BankChunks bc = bank_chunks(nqt, njt, C, seg_cost_of(kTerms), sld(plan_own) != 0);
+  const BankChunks bc = bank_chunks(nqt, njt, C, seg_cost_of(kTerms), sld(plan_own));
   const int cl = c - pick(v_cb);            // chunk inside the object
   const int lane = tid & 63;
   Walk wk;
@@ -1840,8 +1853,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   if (cl < nqt * bc.nfull) {          // aligned chunk: (column block, query tile), one segment
     const int blk = plan_div(cl, nqt);
     wk.qt = cl - blk * nqt;
-    wk.jt0 = blk * bc.Cb;
-    wk.ntl = bc.Cb;
+    bank_block_range(bc, njt, blk, wk.jt0, wk.ntl);
     wk.slot = slot_obj + cl;
     wk.pf_part = wk.qt; wk.pf_nparts = nqt;
     run_segment(blk);

@@ -235,24 +235,52 @@ __host__ __device__ inline int plan_div(int x, int c) {
   return x / c;
 #endif
 }
-struct BankChunks { int C, Cb, nfull, R, nrem, nch, sc; };
-__host__ __device__ inline BankChunks bank_chunks(int nqt, int njt, int C, int segcost = kSegCost, bool own_blocks = false) {
+struct BankChunks { int C, Cb, nfull, R, nrem, nch, sc, eq; };
+// `blocks` is a launch-wide decision of the plan (bank.hip):
+//   0  plain: nfull = njt / C aligned column blocks of C tiles + remainder chunks;
+//   1  "own blocks": as 0, but an object with no more tiles than a chunk is ONE column block of its own length (see below);
+//   2  EQUALISED: every object is cut into nfull = ceil(njt / C) column blocks of (almost) equal length <= C -- block b covers
+//      tiles [b njt / nfull, (b + 1) njt / nfull) -- and there are NO remainder chunks: every chunk is one segment, a pair has
+//      exactly nfull partials.  The plan takes it when it fits the workgroups at (nearly) the chunk length the plain plan found:
+//      the bench launch (objects of 119 tiles, C = 58) then walks 60 + 59 tiles with two partials per pair instead of
+//      58 + 58 + 3 with three, and the multi-segment remainder chunks (a segment's fixed cost is ~12 tiles of the fp16 walk) are gone.
+__host__ __device__ inline BankChunks bank_chunks(int nqt, int njt, int C, int segcost = kSegCost, int blocks = 0) {
   BankChunks k;
   k.C = C;
   k.sc = segcost;
+  k.eq = 0;
   k.Cb = C;                          // length of an aligned column block
+  if (blocks == 2) {
+    k.eq = 1;
+    k.nfull = njt > 0 ? plan_div(njt + C - 1, C) : 0;
+    k.Cb = k.nfull > 0 ? plan_div(njt + k.nfull - 1, k.nfull) : 0;   // (the longest block; bank_block_range() has each block's own)
+    k.R = 0;
+    k.nrem = 0;
+    k.nch = nqt * k.nfull;
+    return k;
+  }
   k.nfull = plan_div(njt, C);
   k.R = njt - k.nfull * C;
   // An object with no more tiles than a chunk is ONE column block of its own length: nqt single-segment chunks that
   // walk the same tiles in lockstep.  As a "remainder" its pairs would be cut at shifted positions, every workgroup
   // would stream its own copy of the tiles, and two such objects per XCD do not fit the L2 (measured, 16 objects of
   // 120 tiles at C = 122: 164 us against 118 us for 15 objects at C = 108).
-  // `own_blocks` is a launch-wide decision of the plan: C is found WITHOUT it (the chunk count then falls as C grows, so
-  // a launch with more pairs than workgroups still fits); it is switched on if the launch still fits with it.
-  if (own_blocks && njt > 0 && njt <= C) { k.Cb = njt; k.nfull = 1; k.R = 0; }
+  // C is found WITHOUT it (the chunk count then falls as C grows, so a launch with more pairs than workgroups still
+  // fits); it is switched on if the launch still fits with it.
+  if (blocks == 1 && njt > 0 && njt <= C) { k.Cb = njt; k.nfull = 1; k.R = 0; }
   k.nrem = k.R > 0 && nqt > 0 ? plan_div(nqt * (k.R + segcost) - segcost + C - 1, C) : 0;   // (no query tile: no chunk)
   k.nch = nqt * k.nfull + k.nrem;
   return k;
+}
+// Tiles [j0, j0 + n) of aligned column block `blk` of an object with njt tiles.
+__host__ __device__ inline void bank_block_range(const BankChunks& k, int njt, int blk, int& j0, int& n) {
+  if (k.eq) {
+    j0 = plan_div(blk * njt, k.nfull);
+    n = plan_div((blk + 1) * njt, k.nfull) - j0;
+  } else {
+    j0 = blk * k.Cb;
+    n = k.Cb;
+  }
 }
 // Smallest chunk length a launch may use: a chunk must amortise its prologue and 128 KB partial
 // (kSplitMinTiles), and a pair may have at most kSplitMax partials (combine's LDS).

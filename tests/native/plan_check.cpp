@@ -10,7 +10,8 @@
 //   3. the segments of a pair sit at positions 0 .. count-1 of the pair's slot list, and that list (the closed form the
 //      last arriver merges from) names exactly their slots;
 //   4. a chunk never starts more segments than the merge scratch allows, no chunk is longer than C tile units;
-//   5. the plan's search for C ends with no more chunks than workgroups, with and without "own column blocks".
+//   5. the plan's search for C ends with no more chunks than workgroups, with and without "own column blocks", and with the
+//      EQUALISED blocks (no remainder chunks; block lengths differ by at most one tile and never exceed C).
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -28,12 +29,14 @@ namespace {
 struct Seg { int qt, j0, n, slot, sself; };
 
 // bank.hip, compute(): the segments of chunk `cl` of one object (slot_obj = 0)
-std::vector<Seg> chunk_segments(const BankChunks& bc, int nqt, int cl) {
+std::vector<Seg> chunk_segments(const BankChunks& bc, int nqt, int njt, int cl) {
   std::vector<Seg> out;
   const int C = bc.C;
   if (cl < nqt * bc.nfull) {
     const int blk = cl / nqt;
-    out.push_back({cl - blk * nqt, blk * bc.Cb, bc.Cb, cl, blk});
+    int j0, n;
+    bank_block_range(bc, njt, blk, j0, n);
+    out.push_back({cl - blk * nqt, j0, n, cl, blk});
     return out;
   }
   const int cr = cl - nqt * bc.nfull;
@@ -67,7 +70,7 @@ int fails = 0;
     }                                                      \
   } while (0)
 
-void check_object(int nqt, int njt, int C, int sc, bool own) {
+void check_object(int nqt, int njt, int C, int sc, int own) {
   const BankChunks bc = bank_chunks(nqt, njt, C, sc, own);
   if (nqt == 0 || njt == 0) {
     CHECK(bc.nch == 0 || njt == 0 || nqt == 0, "nqt %d njt %d C %d", nqt, njt, C);
@@ -76,13 +79,21 @@ void check_object(int nqt, int njt, int C, int sc, bool own) {
     return;
   }
   CHECK(bc.nch == nqt * bc.nfull + bc.nrem, "nch");
-  CHECK(bc.nfull * bc.Cb + bc.R == njt, "tiles: nfull %d Cb %d R %d njt %d", bc.nfull, bc.Cb, bc.R, njt);
+  if (!bc.eq) CHECK(bc.nfull * bc.Cb + bc.R == njt, "tiles: nfull %d Cb %d R %d njt %d", bc.nfull, bc.Cb, bc.R, njt);
+  if (bc.eq) {
+    CHECK(bc.R == 0 && bc.nrem == 0 && bc.Cb <= C, "equalised plan with a remainder / a block longer than C: njt %d C %d Cb %d", njt, C, bc.Cb);
+    for (int b = 0; b < bc.nfull; ++b) {
+      int j0, n;
+      bank_block_range(bc, njt, b, j0, n);
+      CHECK(n >= 1 && n <= bc.Cb && n >= bc.Cb - 1, "equalised block %d of %d: %d tiles (longest %d, njt %d)", b, bc.nfull, n, bc.Cb, njt);
+    }
+  }
   const int nsl = bc.nch + (bc.R > 0 ? nqt : 0);
   std::vector<std::vector<int>> cover(nqt, std::vector<int>(njt, 0));
   std::set<int> slots;
   std::map<int, std::vector<Seg>> by_pair;
   for (int cl = 0; cl < bc.nch; ++cl) {
-    const std::vector<Seg> segs = chunk_segments(bc, nqt, cl);
+    const std::vector<Seg> segs = chunk_segments(bc, nqt, njt, cl);
     int units = 0;
     for (const Seg& s : segs) {
       CHECK(s.n > 0 && s.j0 >= 0 && s.j0 + s.n <= njt, "segment range qt %d j0 %d n %d (njt %d C %d)", s.qt, s.j0, s.n, njt, C);
@@ -118,15 +129,23 @@ void check_launch(const std::vector<int>& nqt, const std::vector<int>& njt, int 
   long long W = 0;
   int njt_max = 0;
   for (size_t o = 0; o < nqt.size(); ++o) { W += (long long)nqt[o] * njt[o]; njt_max = std::max(njt_max, njt[o]); }
-  auto total = [&](int C, bool own) { int n = 0; for (size_t o = 0; o < nqt.size(); ++o) n += bank_chunks(nqt[o], njt[o], C, sc, own).nch; return n; };
+  auto total = [&](int C, int own) { int n = 0; for (size_t o = 0; o < nqt.size(); ++o) n += bank_chunks(nqt[o], njt[o], C, sc, own).nch; return n; };
   int C0 = std::max((int)((W + target - 1) / target), bank_chunk_min(njt_max));
   C0 = (C0 + cq - 1) / cq * cq;
   int it = 0;
-  for (; it < 1024 && total(C0, false) > target; ++it) C0 += (1 + (C0 >> 5) + cq - 1) / cq * cq;
+  for (; it < 1024 && total(C0, 0) > target; ++it) C0 += (1 + (C0 >> 5) + cq - 1) / cq * cq;
   CHECK(it < 1024, "the search for C did not end (W %lld target %d)", W, target);
-  CHECK(total(C0, false) <= target, "more chunks (%d) than workgroups (%d)", total(C0, false), target);
-  const bool own = total(C0, true) <= target;
-  for (size_t o = 0; o < nqt.size(); ++o) check_object(nqt[o], njt[o], C0, sc, own);
+  CHECK(total(C0, 0) <= target, "more chunks (%d) than workgroups (%d)", total(C0, 0), target);
+  // the equalised plan at C0 or one of the next two candidates (the split mode: next one), else own blocks, else plain -- bank.hip
+  int blocks = 0;
+  {
+    const int c1 = C0 + (1 + (C0 >> 5) + cq - 1) / cq * cq, c2 = c1 + (1 + (c1 >> 5) + cq - 1) / cq * cq;
+    const int ceq = total(C0, 2) <= target ? C0 : total(c1, 2) <= target ? c1 : (total(c2, 2) <= target && sc != kSegCost) ? c2 : 0;
+    if (ceq) { C0 = ceq; blocks = 2; }
+  }
+  if (!blocks && total(C0, 1) <= target) blocks = 1;
+  CHECK(total(C0, blocks) <= target, "plan %d: more chunks (%d) than workgroups (%d)", blocks, total(C0, blocks), target);
+  for (size_t o = 0; o < nqt.size(); ++o) check_object(nqt[o], njt[o], C0, sc, blocks);
 }
 
 }  // namespace
@@ -137,7 +156,7 @@ int main() {
     for (int nqt = 0; nqt <= 14; ++nqt)
       for (int njt = 0; njt <= 150; njt += (njt < 40 ? 1 : 7))
         for (int C = 4; C <= 160; C += (C < 30 ? 1 : 5))
-          for (int own = 0; own < 2; ++own) check_object(nqt, njt, C, sc, own != 0);
+          for (int own = 0; own < 3; ++own) check_object(nqt, njt, C, sc, own);
   // 2. whole launches: the shapes of the tests / the bench, and random mixes (empty objects, many equal objects)
   const int targets[] = {256, 232, 209, 192, 64};
   std::mt19937 rng(7);
