@@ -1,36 +1,40 @@
 # -*- coding: utf-8 -*-
 """bench.py -- frames/sec of RMNet's per-frame inference hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1], synthetic): 480x854 clips, 1 object each (K = 2 mask channels),
-memory pinned at T = 5 frames (4 committed + the tentative previous frame); ``--clips-per-gpu`` (default
-4) independent clips are batched on every GPU -- videos share nothing, and a single 480p stream cannot
-fill 256 CUs (measured: 147 frames/s with 1 clip, 176 / 196 / 209 with 2 / 4 / 8).  One "step" = one frame of the
-reference's loop (models/rmnet.py:410-450, utils/helpers.py:55): TinyFlowNet on the frame pair,
-memorise frame t-1 (ResNet-50 memory encoder + KV head + region boxes + bank write), regional query
-boxes from the flow-warped previous mask, query encoder + KV head, fused regional memory read,
-decoder, soft aggregation, soft-max.  fp32 everywhere (the reference's dtype).  Inputs are resident
-in HBM before the timed region.  With N ranks every rank runs its own clips (videos are independent;
-weak scaling, no data-path collective) and ``value`` = N * clips * K / max-over-ranks time.
+N > 1: started from a plain shell (WORLD_SIZE unset) bench.py re-executes itself as N ranks under torch.distributed.run (one
+process per GPU, RCCL over xGMI, rendezvous on 127.0.0.1 at a free port) and rank 0 prints the one JSON line; started BY
+torch.distributed.run (the driver's form) it is one of those ranks.
+
+Workload (BASELINE.json configs[1], synthetic): 480x854 clips, 1 object each (K = 2 mask channels), memory pinned at T = 5
+frames (4 committed + the tentative previous frame); ``--clips-per-gpu`` (default 8) independent clips are batched on every
+GPU -- videos share nothing, and a single 480p stream cannot fill 256 CUs (measured on MI355X: 164 / 194 / 227 / 248 frames/s
+at 1 / 2 / 4 / 8 clips).  One "step" = one frame of the reference's loop (models/rmnet.py:410-450, utils/helpers.py:55):
+TinyFlowNet on the frame pair, memorise frame t-1 (ResNet-50 memory encoder + KV head + region boxes + bank write), regional
+query boxes from the flow-warped previous mask, query encoder + KV head, fused regional memory read, decoder, soft
+aggregation, soft-max.  Convolutions fp32 (the reference's dtype); the arithmetic of the memory read is ``--read-precision``
+('auto' = RMNet's default: fp16 operands for one object per clip, i.e. this workload -- `dtype` says what ran and what its
+parity evidence is).  Inputs are resident in HBM before the timed region.  The frames/s figure is governed by the fp32 MIOpen
+convolutions (85 % of a step's GPU time; the hand-written kernels 9 %): it moves with them, not with the read kernel.  With N
+ranks every rank runs its own clips (videos are independent; weak scaling, no data-path collective) and ``value`` =
+N * clips * K / max-over-ranks time.
 
 The JSON line also carries
-  roofline     -- the dominant hand-written kernel (bk_main = the WHOLE regional memory read: soft-max read,
-                  merge of the partial results, masked cells, the q_val half of the cat -- one launch)
-                  timed live with HIP events recorded on its own stream around every launch of the
-                  timed region.  achieved / peak / frac are SURVEY.md section 8d's figure: algorithmic
-                  bytes per launch / mean duration vs 8 TB/s HBM.  What actually bounds the kernel is the
-                  matrix pipe under the chip's power cap, hence bound = "mfma";
-                  the pipe figures are in roofline.mfma (executed 3-term split-fp16 flops, useful
-                  one-term flops, the 2.5 PFLOP/s dense f16 peak);
-  extras       -- single-stream (eager and HIP-graph replay) and free-running (memorize_every = 5, N = 67,
-                  fed-back masks) fps; whole-loop frames/s for BASELINE configs[2] (5 objects), configs[4]
-                  (720p, 3 objects, T = 20) and the loader's K = 11 channel count; kernel figures for the
-                  hand-written kernels, each against SURVEY.md section 8d's byte formulas (rank 0, N = 1 only);
-  cpu_baseline -- the oracle's CPU restatement of the same path timed on this box's host cores
-                  (rank 0, N = 1 only; bounded sample): BASELINE configs[0] (T = 3, N = 4) over a sweep of
-                  thread counts, value = the best one; the T = 5 pinned shape and the three native ops alone
-                  at the best count and at 8 threads.
+  roofline     -- the dominant hand-written kernel, bk_main = the WHOLE regional memory read in one launch (soft-max read of
+                  the bank, merge of the partial results, masked cells, the q_val half of the cat), timed live with HIP
+                  events recorded on its own stream around every launch of the timed region.  achieved / peak / frac are
+                  SURVEY.md section 8d's figure: algorithmic bytes per launch / mean duration vs 8 TB/s HBM.  What bounds
+                  the kernel is latency (fp16-operand modes: matrix pipe ~20 % busy) resp. the matrix pipe under the power cap
+                  (split mode); roofline.mfma has the pipe figures, roofline.modes the same launches in
+                  the other arithmetic modes (split = fp32-class; qx; f16);
+  extras       -- single-stream (eager and HIP-graph replay) and free-running (memorize_every = 5, N = 67, fed-back masks)
+                  fps; whole-loop frames/s for BASELINE configs[2] (5 objects), configs[4] (720p, 3 objects, T = 20) and the
+                  loader's K = 11 channel count; kernel figures for the hand-written kernels, each against SURVEY.md section
+                  8d's byte formulas (rank 0, N = 1 only; taken in a child process);
+  cpu_baseline -- the oracle's CPU restatement of the same path timed on this box's host cores (rank 0, N = 1 only; bounded
+                  sample): BASELINE configs[0] (T = 3, N = 4) over a sweep of thread counts, value = the best one; the T = 5
+                  pinned shape and the three native ops alone at the best count and at 8 threads.
 """
 
 import argparse
@@ -266,7 +270,7 @@ def kernel_figures(dev, events):
             bank.append(t, k, v, r)
         e3 = (ev[2], ev[3], ev[4])
         ab = algorithmic_bytes(no, T, h, w)
-        for mode in ('split', 'f16'):
+        for mode in ('split', 'f16', 'qx'):
             bank.precision = mode
             for _ in range(3):
                 bank.read(T, k, v, r)
@@ -281,7 +285,7 @@ def kernel_figures(dev, events):
             if mode == 'split':
                 out[name] = row
             else:
-                out[name]['f16_mode'] = {'us': row['us'], 'GBps': row['GBps'], 'hbm_frac': row['hbm_frac']}
+                out[name][mode + '_mode'] = {'us': row['us'], 'GBps': row['GBps'], 'hbm_frac': row['hbm_frac']}
         bank.precision = 'split'
         if name.startswith('cfg3'):
             out['bk_append_5obj_480p'] = gbs(2 * 4 * (DE + DO) * h * w * no, bracket(lambda: bank.append(T - 1, k, v, r)))
@@ -385,11 +389,11 @@ def main():
                     help='independent clips batched on every GPU (one 480p clip cannot fill 256 CUs; measured '
                          'on MI355X: 164 / 194 / 227 / 248 / 247 frames/s at 1 / 2 / 4 / 8 / 10 clips)')
     ap.add_argument('--graph', action='store_true', help='replay the frame step as one captured HIP graph')
-    ap.add_argument('--read-precision', choices=('auto', 'split', 'f16'), default='auto',
+    ap.add_argument('--read-precision', choices=('auto', 'split', 'qx', 'f16'), default='auto',
                     help="arithmetic of the bank read in the timed region: 'auto' (default, = RMNet's default) picks 'f16' for clips with one "
-                         "object -- this workload -- and 'split' for clips with several (profiles/r04_iou_calibration.md); 'split' = fp16 hi/lo "
-                         "pairs, three MFMA terms, fp32-class; 'f16' = fp16 operands, one term, ~2^-11 relative.  The other "
-                         "mode's kernel is timed on the same launches after the timed region and reported under roofline.modes")
+                         "object -- this workload -- and 'qx' for clips with several (profiles/r05_iou_calibration.md); 'split' = fp16 hi/lo "
+                         "pairs, three MFMA terms, fp32-class; 'f16' = fp16 operands, one term; 'qx' = 'f16' with an exact query (two terms for "
+                         "the logits).  The other modes' kernels are timed on the same launches after the timed region (roofline.modes)")
     ap.add_argument('--dist-backend', default=None, help="override the process-group backend ('gloo' lets several "
                     "ranks share one GPU when testing the N>1 path on a 1-GPU box)")
     args = ap.parse_args()
@@ -544,18 +548,20 @@ def main():
     main_ms = [events.elapsed_ms(events.ev[3 * i], events.ev[3 * i + 1]) for i in range(args.steps)]
     comb_ms = [events.elapsed_ms(events.ev[3 * i + 1], events.ev[3 * i + 2]) for i in range(args.steps)]
     # the OTHER arithmetic mode of the same kernel on the same launches (same bank, same boxes), outside the timed region
-    other_mode = 'f16' if args.read_precision == 'split' else 'split'
+    other_modes = [m for m in ('split', 'qx', 'f16') if m != args.read_precision]
     other_ms = None
     if not args.no_extras and not args.extras_child:
-        bank.precision = other_mode
-        for i in range(3):
-            eager_step(i)
-        for i in range(args.steps):
-            eager_step(i, tuple(events.ev[3 * i:3 * i + 3]))
-        torch.cuda.synchronize()
-        net._profile_events = None
+        other_ms = {}
+        for om in other_modes:
+            bank.precision = om
+            for i in range(3):
+                eager_step(i)
+            for i in range(args.steps):
+                eager_step(i, tuple(events.ev[3 * i:3 * i + 3]))
+            torch.cuda.synchronize()
+            net._profile_events = None
+            other_ms[om] = [events.elapsed_ms(events.ev[3 * i], events.ev[3 * i + 2]) - 2e-3 * ev_floor_us for i in range(args.steps)]
         bank.precision = args.read_precision
-        other_ms = [events.elapsed_ms(events.ev[3 * i], events.ev[3 * i + 2]) - 2e-3 * ev_floor_us for i in range(args.steps)]
     main_raw = sum(main_ms) / len(main_ms)
     main_avg = max(main_raw - ev_floor_us * 1e-3, 1e-6)     # kernel time = bracket - empty-bracket floor
     abytes = algorithmic_bytes(B * (K_CH - 1), T_MEM, ctx.h, ctx.w)
@@ -571,15 +577,16 @@ def main():
     qr = qr[:, 1].cpu()
     mq = (qr[:, 1] - qr[:, 0] + 1).clamp(min=0) * (qr[:, 3] - qr[:, 2] + 1).clamp(min=0)
     nqt = (mq + 63) // 64
-    n_terms = 3 if args.read_precision == 'split' else 1
-    mfma_flops = float((nqt * 64 * njt * 32).sum()) * (DE + DO) * 2 * n_terms    # executed: the mode's MFMA terms over the padded tiles
+    n_terms = {'split': 3, 'qx': 2, 'f16': 1}[args.read_precision]         # = the template argument of bk_main
+    s_terms, pv_terms = {'split': (3, 3), 'qx': (2, 1), 'f16': (1, 1)}[args.read_precision]
+    mfma_flops = float((nqt * 64 * njt * 32).sum()) * (DE * s_terms + DO * pv_terms) * 2   # executed: the mode's MFMA terms over the padded tiles
     mfma_tflops = mfma_flops / (main_avg * 1e-3) / 1e12
     useful_flops = float((mq * areas.sum(dim=1)).sum()) * (DE + DO) * 2          # one term over the un-padded regional cells
     useful_tflops = useful_flops / (main_avg * 1e-3) / 1e12
     comb_avg = max(sum(comb_ms) / len(comb_ms) - ev_floor_us * 1e-3, 1e-6)
     op_achieved = abytes / ((main_avg + comb_avg) * 1e-3) / 1e9
     traffic, traffic_note = None, 'no PMC file for this kernel version'
-    tname = 'bk_main_hbm_traffic.json' if args.read_precision == 'split' else 'bk_main_f16_hbm_traffic.json'
+    tname = {'split': 'bk_main_hbm_traffic.json', 'f16': 'bk_main_f16_hbm_traffic.json', 'qx': 'bk_main_qx_hbm_traffic.json'}[args.read_precision]
     tpath = os.path.join(ROOT, 'profiles', tname)                        # from separate --pmc passes (tools/pmc_traffic.sh)
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
@@ -725,7 +732,7 @@ def main():
         torch.cuda.synchronize()
         dt_free_g = time.perf_counter() - t1
         saved_prec = net.read_precision
-        net.read_precision = 'f16' if args.read_precision == 'split' else 'split'
+        net.read_precision = 'f16' if args.read_precision == 'split' else 'split'     # (the timed mode against split, or split against f16)
         net(ff[:, :6], fm[:, :6], tfn(ff[:, :6]), fn_obj[:, :6], 5)          # warm-up
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -778,10 +785,14 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': ('f32 (convs fp32; memory read = split-fp16 MFMA hi*hi+hi*lo+lo*hi with fp32 accumulate, fp32-class accuracy)'
-                      if args.read_precision == 'split' else
-                      'f32 convs; memory read = fp16 operands (K, V, q, P rounded to 11 bits), fp32 accumulate (RMNET_BANK_F16): the frame '
-                      'loop\'s default for clips with one object -- mask IoU vs the CPU path 1.0000 on this workload (profiles/r04_iou_calibration.md)'),
+            'dtype': {'split': 'f32 (convs fp32; memory read = split-fp16 MFMA hi*hi+hi*lo+lo*hi with fp32 accumulate, fp32-class accuracy)',
+                      'qx': 'f32 convs; memory read = fp16 operands with an exact query (q as a hi/lo pair: two MFMA terms for the logits; K, P, V rounded '
+                            'to 11 bits), fp32 accumulate (RMNET_BANK_QX) -- on one-object clips with live mask boundaries: mask IoU vs the CPU path '
+                            '0.99999-1.00000, logits within 1e-4 = the exact-fp32 GPU loop\'s own distance (profiles/r05_iou_calibration.md)',
+                      'f16': 'f32 convs; memory read = fp16 operands (K, V, q, P rounded to 11 bits), fp32 accumulate (RMNET_BANK_F16): the frame '
+                             'loop\'s default for clips with one object -- on one-object 480x854 clips whose masks HAVE a boundary (tests/live_fixture.py) '
+                             'mask IoU vs the CPU path 0.99993-0.99997 and foreground logits within 1.3e-3 (an IoU loss of 1e-3 ~ 2e-2); the same comparison '
+                             'FAILS (0.9969) when the read-out is noised by 1 % (profiles/r05_iou_calibration.md, tests/test_gpu_parity.py)'}[args.read_precision],
             'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: 480x854 synthetic clips, 1 object each (K=2), memory pinned '
                                    'at T=5, TinyFlowNet + memorize + regional read + decoder per frame; '
@@ -797,7 +808,7 @@ def main():
             'roofline': {'bound': 'mfma',
                          'kernel': 'bk_main<%d> = the whole regional memory read in ONE launch (%s MFMA read of the bank, merge of the '
                                    'partial results by the last workgroup of every query tile, masked cells, q_val half of the cat)'
-                                   % (n_terms, 'split-fp16 (3-term)' if n_terms == 3 else 'fp16-operand (1-term)'),
+                                   % (n_terms, {3: 'split-fp16 (3-term)', 2: 'fp16-operand, exact-query (2 + 1 terms)', 1: 'fp16-operand (1-term)'}[n_terms]),
                          'read_precision': args.read_precision, 'read_precision_requested': requested_precision,
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                          'definition': 'SURVEY.md 8d / BASELINE.json: algorithmic bytes per launch (%d B = %d object-frames x 31,518,720 B) / '
@@ -822,17 +833,18 @@ def main():
                                    'round 2 had its combine kernel)'},
         }
         if other_ms is not None:
-            o_us = 1e3 * sum(other_ms) / len(other_ms)
-            this = {'avg_us': round((main_avg + comb_avg) * 1e3, 2), 'GBps': round(op_achieved, 1), 'frac': round(op_achieved / HBM_PEAK_GBS, 4)}
-            other = {'avg_us': round(o_us, 2), 'GBps': round(abytes / o_us / 1e3, 1), 'frac': round(abytes / o_us / 1e3 / HBM_PEAK_GBS, 4)}
-            line['roofline']['modes'] = {
-                args.read_precision: this, other_mode: other,
-                'note': "the same launches (same bank, same boxes) in both arithmetic modes of the kernel, whole read, HIP events on the "
-                        "launch stream; the top-level figures are the timed region's mode ('%s').  split = fp32-class (error 1e-7), the loop's default "
-                        "for clips with several objects; f16 = RMNET_BANK_F16: fp16 operands, fp32 accumulate, read-out error ~2^-11 of the values "
-                        "(3e-4 worst, 5e-6 typical), the loop's default for one object per clip (this workload): whole-clip mask IoU vs the CPU path "
-                        "1.0000; with 3 / 5 objects per clip 0.9991-0.9995 / 0.9986-0.9992 on random-init weights, exact fp32 on the GPU >= 0.9997 "
-                        "(profiles/r04_iou_calibration.md, tests/test_gpu_parity.py)" % args.read_precision}
+            modes = {args.read_precision: {'avg_us': round((main_avg + comb_avg) * 1e3, 2), 'GBps': round(op_achieved, 1),
+                                           'frac': round(op_achieved / HBM_PEAK_GBS, 4)}}
+            for om, ms in other_ms.items():
+                o_us = 1e3 * sum(ms) / len(ms)
+                modes[om] = {'avg_us': round(o_us, 2), 'GBps': round(abytes / o_us / 1e3, 1), 'frac': round(abytes / o_us / 1e3 / HBM_PEAK_GBS, 4)}
+            modes['note'] = ("the same launches (same bank, same boxes) in the three arithmetic modes of the kernel, whole read, HIP events on the "
+                             "launch stream; the top-level figures are the timed region's mode ('%s').  split = fp32-class (error 1e-7); f16 = RMNET_BANK_F16: "
+                             "fp16 operands, fp32 accumulate, the loop's default for one object per clip (this workload); qx = RMNET_BANK_QX: f16 with an exact "
+                             "query, the loop's default for several objects per clip.  Whole-clip mask IoU vs the CPU path (profiles/r05_iou_calibration.md): "
+                             "one object, live mask boundaries: f16 0.99993-0.99997, qx / split / exact fp32 0.99999-1.00000; 3 / 5 objects: exact fp32 "
+                             ">= 0.9997, qx >= 0.9993, f16 0.9986-0.9995" % args.read_precision)
+            line['roofline']['modes'] = modes
         if extras is not None and extras.get('single_stream_fps'):
             line['config']['workload'] += ' -- value = %d clips batched per GPU; ONE 480p stream alone: %.1f frames/s' % (B, extras['single_stream_fps'])
         else:

@@ -28,7 +28,7 @@ extern "C" {
 #define RMNET_ABI_VERSION 5   /* 2: rmnet_bank_read_f32 takes a mutable bank; rmnet_bank_area_offset.  3: RMNET_MR_F16 / RMNET_BANK_F16,
                                * rmnet_bank_read_f32_at takes flags.  4: banks of any Tcap, chunked reads of T > 2048 (rmnet_bank_read_workspace_bytes_for);
                                * the read counts out-of-window query elements; sticky error bits + time-out word behind the overflow word.
-                               * 5: RMNET_MR_MIXED / RMNET_BANK_MIXED (logits in three split-fp16 terms, O = V P in one); a pair whose merge timed out is
+                               * 5: RMNET_MR_QX / RMNET_BANK_QX (fp16 operands with an exact query); a pair whose merge timed out is
                                * written as NaN; the overflow word is a zero / non-zero flag, not an element count */
 
 enum {
@@ -123,16 +123,12 @@ int rmnet_boxes_to_cell_rects_i32(const int32_t *bboxes, int n_boxes, int k_per_
 #define RMNET_MR_EXACT_FP32 2    /* fast shape only: skip the split-fp16 bank, run the exact-fp32 MFMA kernel */
 #define RMNET_MR_F16 4           /* fast shape only: fp16 operands (hi planes of the bank), fp32 accumulate */
 #define RMNET_BANK_F16 4         /* the same switch for rmnet_bank_read_f32_at */
-#define RMNET_MR_MIXED 8         /* fast shape only: the logits S = K^T q in the default's three split-fp16 terms (fp32-class), the soft-max
-                                  * weights and the values rounded to fp16 for O = V P (one term, hi plane of V).  Error of a read-out:
-                                  * P's and V's roundings only (2^-12 relative each, averaged over the cells that contribute) -- the |S| 2^-11
-                                  * weight error of RMNET_MR_F16, which is what costs mask IoU on multi-object clips, is gone.  About the
-                                  * speed of RMNET_MR_F16.  Mutually exclusive with it. */
-#define RMNET_BANK_MIXED 8       /* the same switch for rmnet_bank_read_f32_at */
-#define RMNET_MR_QX 16           /* fast shape only: RMNET_MR_F16 with an EXACT QUERY -- q enters the logits as a hi/lo pair (two MFMA terms), K, P
+#define RMNET_MR_QX 8            /* fast shape only: RMNET_MR_F16 with an EXACT QUERY -- q enters the logits as a hi/lo pair (two MFMA terms), K, P
                                   * and V stay rounded to fp16.  q's rounding is the one logit error that is coherent over all memory cells of
-                                  * a query; removing it recovers most of what RMNET_MR_F16 costs in mask IoU, at ~10 % of its speed. */
-#define RMNET_BANK_QX 16         /* the same switch for rmnet_bank_read_f32_at */
+                                  * a query; removing it recovers most of what RMNET_MR_F16 costs in mask IoU (measured on whole clips against
+                                  * the CPU path: profiles/r05_iou_calibration.md) for 3 % (frame loop) to 9 % (back to back) of its speed.
+                                  * Mutually exclusive with RMNET_MR_F16. */
+#define RMNET_BANK_QX 8          /* the same switch for rmnet_bank_read_f32_at */
 
 size_t rmnet_memory_read_workspace_bytes(int no, int De, int Do, int T, int h, int w, int flags);
 int rmnet_memory_read_f32(const float *m_key, const float *m_val, const float *q_key,
@@ -194,8 +190,8 @@ int rmnet_memory_read_f32_ev(const float *m_key, const float *m_val, const float
  *       read it in chunks of 2048 slots and merge the chunks' read-outs by their soft-max state (m, l) -- the same merge the
  *       kernel applies to the partial results of one launch -- in a workspace of rmnet_bank_read_workspace_bytes_for(...) bytes.
  * rmnet_bank_read_f32_at(..., flags): 0 = the arithmetic above; RMNET_BANK_F16 = hi planes only (see RMNET_MR_F16: fp16
- *       operands, fp32 accumulate, ~2^-11 relative, 1.5-2x as fast); RMNET_BANK_MIXED = logits in three terms, O = V P in one
- *       (see RMNET_MR_MIXED).  The bank is the same in every mode: a clip can be memorised once and read in all three.
+ *       operands, fp32 accumulate, ~2^-11 relative, 1.5-2x as fast); RMNET_BANK_QX = the same with an exact query (see
+ *       RMNET_MR_QX).  The bank is the same in every mode: a clip can be memorised once and read in all three.
  * ------------------------------------------------------------------------------------------- */
 size_t rmnet_bank_bytes(int no, int Tcap, int h, int w);
 size_t rmnet_bank_overflow_offset(int no, int Tcap, int h, int w);

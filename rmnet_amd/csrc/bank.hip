@@ -808,62 +808,41 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
 struct L2Prefetch {
   static constexpr int kLinesK = kJT * kDe * 2 / 128, kLinesV = kDo * kJT * 2 / 128, kLinesT = kLinesK + kLinesV;   // 64 + 256 per tile
   Cursor c;
-  const char *kh, *kl, *vh;
+  const char *kh, *vh;
   size_t so0, tps, hwp;
   int jt0, ntl, part, nparts;
   unsigned patch;
   __device__ inline void init(const BankView& b, const Walk& wk, const int* tpre, char* lds_base, int wave_slot) {
     c.init(tpre, wk.t, wk.jt0 + wk.ntl - 1);
-    kh = b.kh; kl = b.kl; vh = b.vh;
+    kh = b.kh; vh = b.vh;
     so0 = (size_t)wk.o * b.Tcap; tps = (size_t)(b.hwp / kJT); hwp = (size_t)b.hwp;
     jt0 = wk.jt0; ntl = wk.ntl; part = wk.pf_part; nparts = wk.pf_nparts;
     patch = __builtin_amdgcn_readfirstlane(
         (unsigned)(size_t)(__attribute__((address_space(3))) char*)(lds_base + kLdsBytes - 12 * 256 + wave_slot * 256));
   }
-  __device__ inline void dma(const char* ad) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(ad), "s"(patch) : "memory");
-  }
-  // the lines of step `step`, this workgroup's share, spread over waves w = 0 .. nw - 1.
-  // kMode 1 (fp16 operands): a step = two tiles, hi planes of K and V.  kMode 2 (mixed): a step = one tile, K hi + K lo + V hi.
-  template <int kMode>
+  // the lines of step `step`, this workgroup's share, spread over waves w = 0 .. nw - 1
   __device__ inline void touch(int step, int w, int nw, int lane) {
     if (nparts <= 0) return;
-    if constexpr (kMode != 2) {
-      const int ja = jt0 + 2 * step;
-      if (ja >= jt0 + ntl) return;                                         // (wave-uniform)
-      const int la = c.seek(ja);
-      const char* ka = kh + ((so0 + c.tt) * hwp + (size_t)la * kJT) * kDe * sizeof(_Float16);
-      const char* va = vh + ((so0 + c.tt) * tps + la) * (size_t)(kDo * kJT * 2);
-      const int lb = c.seek(ja + 1);                                       // (clamped to the segment's last tile)
-      const char* kb2 = kh + ((so0 + c.tt) * hwp + (size_t)lb * kJT) * kDe * sizeof(_Float16);
-      const char* vb2 = vh + ((so0 + c.tt) * tps + lb) * (size_t)(kDo * kJT * 2);
-      const int nl = (2 * kLinesT + nparts - 1) / nparts;                  // lines of this workgroup
-      for (int l0 = w * 64; l0 < nl; l0 += nw * 64) {                      // (wave-uniform trip count)
-        int i = (l0 + lane) * nparts + part;
-        i = i < 2 * kLinesT ? i : part;                                    // (past the share: a duplicate of its first line)
-        const bool second = i >= kLinesT;
-        const int r = second ? i - kLinesT : i;
-        const bool isk = r < kLinesK;
-        const char* base = second ? (isk ? kb2 : vb2) : (isk ? ka : va);
-        dma(base + (size_t)(isk ? r : r - kLinesK) * 128);
-      }
-    } else {
-      const int ja = jt0 + step;
-      if (ja >= jt0 + ntl) return;
-      const int la = c.seek(ja);
-      const size_t koff = ((so0 + c.tt) * hwp + (size_t)la * kJT) * kDe * sizeof(_Float16);
-      const char* va = vh + ((so0 + c.tt) * tps + la) * (size_t)(kDo * kJT * 2);
-      constexpr int kAll = 2 * kLinesK + kLinesV;
-      const int nl = (kAll + nparts - 1) / nparts;
-      for (int l0 = w * 64; l0 < nl; l0 += nw * 64) {
-        int i = (l0 + lane) * nparts + part;
-        i = i < kAll ? i : part;
-        const char* ad = i < kLinesK ? kh + koff + (size_t)i * 128
-                         : (i < 2 * kLinesK ? kl + koff + (size_t)(i - kLinesK) * 128 : va + (size_t)(i - 2 * kLinesK) * 128);
-        dma(ad);
-      }
+    const int ja = jt0 + 2 * step;
+    if (ja >= jt0 + ntl) return;                                         // (wave-uniform)
+    const int la = c.seek(ja);
+    const char* ka = kh + ((so0 + c.tt) * hwp + (size_t)la * kJT) * kDe * sizeof(_Float16);
+    const char* va = vh + ((so0 + c.tt) * tps + la) * (size_t)(kDo * kJT * 2);
+    const int lb = c.seek(ja + 1);                                       // (clamped to the segment's last tile)
+    const char* kb2 = kh + ((so0 + c.tt) * hwp + (size_t)lb * kJT) * kDe * sizeof(_Float16);
+    const char* vb2 = vh + ((so0 + c.tt) * tps + lb) * (size_t)(kDo * kJT * 2);
+    const int nl = (2 * kLinesT + nparts - 1) / nparts;                  // lines of this workgroup
+    for (int l0 = w * 64; l0 < nl; l0 += nw * 64) {                      // (wave-uniform trip count)
+      int i = (l0 + lane) * nparts + part;
+      i = i < 2 * kLinesT ? i : part;                                    // (past the share: a duplicate of its first line)
+      const bool second = i >= kLinesT;
+      const int r = second ? i - kLinesT : i;
+      const bool isk = r < kLinesK;
+      const char* base = second ? (isk ? kb2 : vb2) : (isk ? ka : va);
+      const char* ad = base + (size_t)(isk ? r : r - kLinesK) * 128;
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(ad), "s"(patch) : "memory");
     }
   }
 };
@@ -887,18 +866,11 @@ struct L2Prefetch {
 // Barriers: A (K steps 0..3 in the ring), B (P(0), P(1) published; ring slot 0 read), C (K step 4 in slot 0),
 // then one per step.
 // ================================================================================================================
-// kMode 1 = the fp16-operand mode as described above.
-// kMode 3 = fp16 operands with an EXACT QUERY (RMNET_BANK_QX): kMode 1 plus the lo plane of q against the same K fragments (16 more
-// MFMAs per step, producers only).  The rounding of q is the one logit error that is COHERENT over all memory cells of a query
-// (K's roundings are independent from cell to cell and average out in the weighted sum): emulated on the CPU path it is most of
-// what the fp16-operand read costs in mask IoU on multi-object clips (profiles/r05_iou_emulation.md).
-// kMode 2 = the MIXED mode (RMNET_BANK_MIXED): the same pipeline with a step of ONE tile whose two ring planes are the hi and the
-// lo plane of its keys -- the logits S = K^T q are computed in the split mode's three terms (hi*hi + hi*lo + lo*hi: fp32-class,
-// 24 MFMAs per tile in two accumulator chains), the soft-max weights and the values enter the O = V P MFMAs rounded to fp16
-// (one term, hi plane of V only; the denominator is the sum of the ROUNDED weights).  Why: on whole clips it is the logits'
-// rounding that costs mask IoU (|S| 2^-11 relative error of a weight, amplified by the soft aggregation over several objects),
-// not the rounding of P and V (profiles/r05_iou_*.md: emulated on the CPU path and measured here).
-template <int kMode>
+// kQx (RMNET_BANK_QX) = the same walk with an EXACT QUERY: q enters the logits as a hi/lo pair -- the lo plane against the same K
+// fragments, 16 more MFMAs per step, producers only; K, P and V stay rounded to fp16.  The rounding of q is the one logit error
+// that is COHERENT over all memory cells of a query (K's roundings are independent from cell to cell and average out in the
+// weighted sum): on whole clips it is most of what the fp16-operand read costs in mask IoU (profiles/r05_iou_calibration.md).
+template <bool kQx>
 __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
                                          const int* tpre, const int* tarea, int wave, int lane, long long t_entry,
                                          float& m_out, float& l_out) {
@@ -906,10 +878,7 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
   const int o = wk.o;
   const int l15 = lane & 15, g = lane >> 4;
   const int jt0 = wk.jt0, ntl = wk.ntl;
-  constexpr int kTPS = kMode != 2 ? 2 : 1;           // tiles per step
-  constexpr int kNC = kMode != 2 ? 4 : 2;            // accumulator chains of S per step (16 cells each)
-  constexpr int kPf = kMode != 2 ? BK_PF : 2 * BK_PF;   // L2 prefetch distance in steps
-  const int nst = (ntl + kTPS - 1) / kTPS;           // steps (fp16 mode: the last one may be half empty)
+  const int nst = (ntl + 1) >> 1;                    // steps of two tiles (the last one may be half empty)
 #if BK_TRACE
   long long* trc = reinterpret_cast<long long*>(a.ws_o + (size_t)a.trace_slot * (size_t)kDo * kQT);
   int trn = 0;
@@ -917,7 +886,7 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
   if (trace_on) trc[trn++] = t_entry;
 #endif
   BK_STAMP();
-  half8 qh[4], ql[kMode != 1 ? 4 : 1];
+  half8 qh[4], ql[kQx ? 4 : 1];
   {
     const int qn = wk.qt * kQT + wave * 16 + l15;
     const bool qvalid = qn < wk.Mq;
@@ -933,7 +902,7 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float x = qb[(size_t)(32 * ks + 8 * g + e) * b.hw] * keep;   // (range: query_range_check)
-        if constexpr (kMode != 1) {
+        if constexpr (kQx) {
           _Float16 hi, lo;
           split_f16(x, hi, lo);
           qh[ks][e] = hi; ql[ks][e] = lo;
@@ -950,8 +919,7 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
   L2Prefetch pf;
   if (BK_PF) pf.init(b, wk, tpre, Kl_, wave);
 
-  // fp16 mode: tile A cells 0-15 / 16-31, tile B cells 0-15 / 16-31.  Mixed mode: hi plane cells 0-15 / 16-31, lo plane likewise.
-  struct Frags { half8 a0[4], a1[4], b0[4], b1[4]; };
+  struct Frags { half8 a0[4], a1[4], b0[4], b1[4]; };   // tile A cells 0-15 / 16-31, tile B cells 0-15 / 16-31
   auto k_frags = [&](Frags& f, int kslot) {             // 16 conflict-free ds_read_b128 (XOR-swizzled rows)
     const char* kb = Kl_ + kslot * 2 * kKbuf;
 #pragma unroll
@@ -963,68 +931,49 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
       f.b1[ks] = *reinterpret_cast<const half8*>(kb + kKbuf + (16 + l15) * 256 + sw);
     }
   };
-  struct S4 { f32x4 s[kNC]; };
-  auto s_mfma = [&](const Frags& f, S4& r) {
-    if constexpr (kMode != 2) {                      // four independent chains, interleaved
+  struct S4 { f32x4 s[4]; };
+  auto s_mfma = [&](const Frags& f, S4& r) {         // four independent chains, interleaved
 #pragma unroll
-      for (int c = 0; c < 4; ++c) r.s[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if constexpr (kMode == 3) {                    // exact query: the lo plane of q against the same K fragments, small terms first
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          r.s[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a0[ks], ql[ks], r.s[0], 0, 0, 0);
-          r.s[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a1[ks], ql[ks], r.s[1], 0, 0, 0);
-          r.s[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.b0[ks], ql[ks], r.s[2], 0, 0, 0);
-          r.s[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.b1[ks], ql[ks], r.s[3], 0, 0, 0);
-        }
-      }
+    for (int c = 0; c < 4; ++c) r.s[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (kQx) {                             // the query's lo plane first (small terms first)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        r.s[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a0[ks], qh[ks], r.s[0], 0, 0, 0);
-        r.s[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a1[ks], qh[ks], r.s[1], 0, 0, 0);
-        r.s[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.b0[ks], qh[ks], r.s[2], 0, 0, 0);
-        r.s[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.b1[ks], qh[ks], r.s[3], 0, 0, 0);
-      }
-    } else {                                         // two chains; the three split terms inside a chain, small terms first
-      r.s[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-      r.s[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        r.s[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.b0[ks], qh[ks], r.s[0], 0, 0, 0);
-        r.s[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.b1[ks], qh[ks], r.s[1], 0, 0, 0);
         r.s[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a0[ks], ql[ks], r.s[0], 0, 0, 0);
         r.s[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a1[ks], ql[ks], r.s[1], 0, 0, 0);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        r.s[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a0[ks], qh[ks], r.s[0], 0, 0, 0);
-        r.s[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a1[ks], qh[ks], r.s[1], 0, 0, 0);
+        r.s[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.b0[ks], ql[ks], r.s[2], 0, 0, 0);
+        r.s[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.b1[ks], ql[ks], r.s[3], 0, 0, 0);
       }
     }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      r.s[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a0[ks], qh[ks], r.s[0], 0, 0, 0);
+      r.s[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a1[ks], qh[ks], r.s[1], 0, 0, 0);
+      r.s[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.b0[ks], qh[ks], r.s[2], 0, 0, 0);
+      r.s[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.b1[ks], qh[ks], r.s[3], 0, 0, 0);
+    }
   };
-  // nva / nvb = cells of the step's tiles that exist (0 for a phantom tile past the split's end; nvb is kJT in the mixed mode).
-  // Its own basic block (wave-uniform branch), so that the rest of an iteration is ONE scheduling region.
+  // nva / nvb = cells of the step's two tiles that exist (0 for a phantom tile past the split's end).  Its own basic
+  // block (wave-uniform branch), so that the rest of an iteration is ONE scheduling region.
   auto mask_ragged = [&](S4& r, int nva, int nvb) {
     if (nva < kJT || nvb < kJT) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         r.s[0][i] = (4 * g + i < nva) ? r.s[0][i] : -INFINITY;
         r.s[1][i] = (16 + 4 * g + i < nva) ? r.s[1][i] : -INFINITY;
-        if constexpr (kMode != 2) {
-          r.s[2][i] = (4 * g + i < nvb) ? r.s[2][i] : -INFINITY;
-          r.s[3][i] = (16 + 4 * g + i < nvb) ? r.s[3][i] : -INFINITY;
-        }
+        r.s[2][i] = (4 * g + i < nvb) ? r.s[2][i] : -INFINITY;
+        r.s[3][i] = (16 + 4 * g + i < nvb) ? r.s[3][i] : -INFINITY;
       }
     }
   };
   auto soft_max = [&](const S4& r, int pbuf) {
-    float sv[4 * kNC];
+    float sv[16];
 #pragma unroll
-    for (int c = 0; c < kNC; ++c)
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int i = 0; i < 4; ++i) sv[4 * c + i] = r.s[c][i];
     float tmax = sv[0];
 #pragma unroll
-    for (int e = 1; e < 4 * kNC; ++e) tmax = fmaxf(tmax, sv[e]);
+    for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, sv[e]);
     tmax = group4_max(tmax);
     const bool bump = tmax > mref + kDeferRaw;
     const float alpha = bump ? __builtin_amdgcn_exp2f((mref - tmax) * kSraw) : 1.0f;
@@ -1035,35 +984,29 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
     for (int i = 0; i < 4; ++i) {
       const half2 ha = {(_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sv[2 * i], kSraw, nm)),
                         (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sv[2 * i + 1], kSraw, nm))};
+      const half2 hb = {(_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sv[8 + 2 * i], kSraw, nm)),
+                        (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sv[8 + 2 * i + 1], kSraw, nm))};
       pa[i] = __builtin_bit_cast(unsigned, ha);
-      if constexpr (kMode != 2) {
-        const half2 hb = {(_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sv[8 + 2 * i], kSraw, nm)),
-                          (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sv[8 + 2 * i + 1], kSraw, nm))};
-        pb_[i] = __builtin_bit_cast(unsigned, hb);
-      }
+      pb_[i] = __builtin_bit_cast(unsigned, hb);
     }
     char* pb = Pl_ + pbuf * kPbuf + wave * 2048 + lane * 16;
     *reinterpret_cast<u32x4*>(pb) = pa;
-    if constexpr (kMode != 2) *reinterpret_cast<u32x4*>(pb + 1024) = pb_;
+    *reinterpret_cast<u32x4*>(pb + 1024) = pb_;
     if (g == 0) Al[pbuf * kQT + l15 * 4 + wave] = alpha;
     // denominator: every row of ones x P is the column sum of the rounded weights of query l15
     f32x4 lc = {lsum * alpha, 0.f, 0.f, 0.f};
     lc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, __builtin_bit_cast(half8, pa), lc, 0, 0, 0);
-    if constexpr (kMode != 2) lc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, __builtin_bit_cast(half8, pb_), lc, 0, 0, 0);
+    lc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, __builtin_bit_cast(half8, pb_), lc, 0, 0, 0);
     lsum = lc[0];
   };
   Cursor cs;                       // walks ahead of the soft-max: the cell counts of a step are fetched an iteration early
   cs.init(tpre, wk.t, jt0 + ntl - 1);
   auto step_valid = [&](int step, int& nva, int& nvb) {
-    const int ja = jt0 + kTPS * step;
+    const int ja = jt0 + 2 * step;
     const int la = cs.seek(ja);
     nva = ja < jt0 + ntl ? tarea[cs.tt] - la * kJT : 0;
-    if constexpr (kMode != 2) {
-      const int lb = cs.seek(ja + 1);
-      nvb = ja + 1 < jt0 + ntl ? tarea[cs.tt] - lb * kJT : 0;
-    } else {
-      nvb = kJT;
-    }
+    const int lb = cs.seek(ja + 1);
+    nvb = ja + 1 < jt0 + ntl ? tarea[cs.tt] - lb * kJT : 0;
   };
   S4 sp;                           // S of the step whose soft-max comes next
   Frags f;
@@ -1107,9 +1050,9 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
     // for the pipe behind the consumers' (~40 cycles each, trace) while its VALU chain sits behind them in program order
 #if BK_F16_INTERLEAVE
 #pragma unroll
-    for (int i = 0; i < (kMode == 1 ? 16 : kMode == 3 ? 32 : 24); ++i) {
+    for (int i = 0; i < (kQx ? 32 : 16); ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, kMode == 1 ? BK_F16_INTERLEAVE : (BK_F16_INTERLEAVE + 1) / 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, kQx ? (BK_F16_INTERLEAVE + 1) / 2 : BK_F16_INTERLEAVE, 0);
     }
 #endif
     __builtin_amdgcn_sched_barrier(0);
@@ -1120,7 +1063,7 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
 #endif
     step_valid(n + 3, nva, nvb);                     // (LDS round trips: they end under the barrier)
     pbuf = pbuf == 2 ? 0 : pbuf + 1;
-    if (BK_PF) pf.touch<kMode>(n + kPf, wave, kProducers, lane);
+    if (BK_PF) pf.touch(n + BK_PF, wave, kProducers, lane);
     BK_STAMP();   // K frags requested
     __syncthreads();
     BK_STAMP();   // after barrier
@@ -1128,11 +1071,10 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
   m_out = mref * kSraw;
   l_out = lsum;
   query_range_check(b, qh, wk.qt * kQT + wave * 16 + l15 < wk.Mq);
-  if (BK_PF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the patch is free again; the youngest touch is kPf steps old)
+  if (BK_PF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the patch is free again; the youngest touch is BK_PF steps old)
   BK_STAMP();
 }
 
-template <int kMode>
 __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
                                          const int* tpre, int wave, int lane, long long t_entry,
                                          f32x4 (&acc)[kCDT][4]) {
@@ -1140,9 +1082,7 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
   const int o = wk.o;
   const int l15 = lane & 15;
   const int jt0 = wk.jt0, ntl = wk.ntl;
-  constexpr int kTPS = kMode != 2 ? 2 : 1;           // tiles per step (producer_loop_f16)
-  constexpr int kPf = kMode != 2 ? BK_PF : 2 * BK_PF;
-  const int nst = (ntl + kTPS - 1) / kTPS;
+  const int nst = (ntl + 1) >> 1;
 #if BK_TRACE
   long long* trc = reinterpret_cast<long long*>(a.ws_o + (size_t)a.trace_slot * (size_t)kDo * kQT) + 1024;
   int trn = 0;
@@ -1155,25 +1095,19 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
   const int dt0 = kCDT * (wave - kProducers);
   const size_t vlane = (size_t)(dt0 * 64 + lane) * 16;
   auto v_tile = [&](int tt, int ll) { return ((so0 + tt) * tiles_per_slot + ll) * (size_t)(kDo * kJT * 2) + vlane; };
-  // K ring: ring slot = step & 3.  fp16 mode: plane 0 of a slot = the step's first tile, plane 1 = its second tile (hi planes
-  // both); mixed mode: plane 0 = the hi plane of the step's tile, plane 1 = its lo plane.  A tile is one contiguous 8 KB block
-  // per plane = 512 chunks of 16 B; consumer thread ct moves chunk ct of both planes.  LDS image as in the split mode: row = cell
-  // (256 B), chunk c of row r stored at chunk c ^ (r & 15).
+  // K ring: ring slot = step & 3; plane 0 of a slot = the step's first tile, plane 1 = its second tile (hi planes
+  // both).  A tile is one contiguous 8 KB block = 512 chunks of 16 B; consumer thread ct moves chunk ct of both
+  // tiles.  LDS image as in the split mode: row = cell (256 B), chunk c of row r stored at chunk c ^ (r & 15).
   const int ct = (wave - kProducers) * 64 + lane;
   const int crow = ct >> 4;
   const int kdst = crow * 256 + (((ct & 15) ^ (crow & 15)) << 4);
   Cursor ck;
   ck.init(tpre, wk.t, jt0 + ntl - 1);
-  auto k_load = [&](half8 (&kr)[2], int step) {      // both planes of a step (clamped past the end)
-    const int la = ck.seek(jt0 + kTPS * step);
-    const size_t offa = ((so0 + ck.tt) * b.hwp + (size_t)la * kJT) * kDe * sizeof(_Float16) + (size_t)ct * 16;
-    kr[0] = *reinterpret_cast<const half8*>(b.kh + offa);
-    if constexpr (kMode != 2) {
-      const int lb = ck.seek(jt0 + 2 * step + 1);
-      kr[1] = *reinterpret_cast<const half8*>(b.kh + ((so0 + ck.tt) * b.hwp + (size_t)lb * kJT) * kDe * sizeof(_Float16) + (size_t)ct * 16);
-    } else {
-      kr[1] = *reinterpret_cast<const half8*>(b.kl + offa);
-    }
+  auto k_load = [&](half8 (&kr)[2], int step) {      // both tiles of a step (clamped past the end)
+    const int la = ck.seek(jt0 + 2 * step);
+    kr[0] = *reinterpret_cast<const half8*>(b.kh + ((so0 + ck.tt) * b.hwp + (size_t)la * kJT) * kDe * sizeof(_Float16) + (size_t)ct * 16);
+    const int lb = ck.seek(jt0 + 2 * step + 1);
+    kr[1] = *reinterpret_cast<const half8*>(b.kh + ((so0 + ck.tt) * b.hwp + (size_t)lb * kJT) * kDe * sizeof(_Float16) + (size_t)ct * 16);
   };
   auto k_store = [&](const half8 (&kr)[2], int slot) {
     char* d = Kl_ + slot * 2 * kKbuf + kdst;
@@ -1193,26 +1127,25 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
     k_store(k2, 2);
     k_store(k3, 3);
   }
-  half8 va[kCDT], vb[kMode != 2 ? kCDT : 1];   // V fragments of the step's tile(s)
+  half8 va[kCDT], vb[kCDT];        // V fragments of the step's two tiles
   Cursor cv;
   cv.init(tpre, wk.t, jt0 + ntl - 1);
   {
     const int la = cv.seek(jt0);
     const size_t offa = v_tile(cv.tt, la);
+    const int lb = cv.seek(jt0 + 1);
+    const size_t offb = v_tile(cv.tt, lb);
 #pragma unroll
-    for (int dt = 0; dt < kCDT; ++dt) va[dt] = *reinterpret_cast<const half8*>(b.vh + offa + dt * 1024);
-    if constexpr (kMode != 2) {
-      const int lb = cv.seek(jt0 + 1);
-      const size_t offb = v_tile(cv.tt, lb);
-#pragma unroll
-      for (int dt = 0; dt < kCDT; ++dt) vb[dt] = *reinterpret_cast<const half8*>(b.vh + offb + dt * 1024);
+    for (int dt = 0; dt < kCDT; ++dt) {
+      va[dt] = *reinterpret_cast<const half8*>(b.vh + offa + dt * 1024);
+      vb[dt] = *reinterpret_cast<const half8*>(b.vh + offb + dt * 1024);
     }
   }
 #pragma unroll
   for (int dt = 0; dt < kCDT; ++dt)
 #pragma unroll
     for (int it = 0; it < 4; ++it) acc[dt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
-  half8 pa[4], pb[kMode != 2 ? 4 : 1];   // P fragments of the current step
+  half8 pa[4], pb[4];              // P fragments of the current step
   f32x4 al;                        // its rescale factors
   auto p_frags = [&](int buf) {
     const char* pfr = Pl_ + buf * kPbuf;
@@ -1220,7 +1153,7 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       pa[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + lane * 16);
-      if constexpr (kMode != 2) pb[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + 1024 + lane * 16);
+      pb[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + 1024 + lane * 16);
     }
   };
   __syncthreads();                                   // A: K steps 0..3 in the ring
@@ -1228,7 +1161,7 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
     L2Prefetch pf;
     pf.init(b, wk, tpre, Kl_, wave);
 #pragma unroll 1
-    for (int s_ = 1; s_ < kPf; ++s_) pf.touch<kMode>(s_, wave - kProducers, kConsumers, lane);   // (step 0 and the K tiles of steps 1..4 are demand loads)
+    for (int s_ = 1; s_ < BK_PF; ++s_) pf.touch(s_, wave - kProducers, kConsumers, lane);   // (step 0 and the K tiles of steps 1..4 are demand loads)
   }
   __syncthreads();                                   // B: P(0), P(1) visible; ring slot 0 free
   k_store(kr, 0);                                    // step 4
@@ -1238,14 +1171,12 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
   BK_STAMP();
   int pnext = 1;                                     // (n + 1) % 3
   // addresses of the NEXT step's V tiles: found before the barrier, so that an iteration starts with MFMAs
-  const char *nva, *nvb = nullptr;
+  const char *nva, *nvb;
   auto v_next = [&](int step) {
-    const int la = cv.seek(jt0 + kTPS * step);       // (clamped past the end)
+    const int la = cv.seek(jt0 + 2 * step);          // (clamped past the end)
     nva = b.vh + v_tile(cv.tt, la);
-    if constexpr (kMode != 2) {
-      const int lb = cv.seek(jt0 + 2 * step + 1);
-      nvb = b.vh + v_tile(cv.tt, lb);
-    }
+    const int lb = cv.seek(jt0 + 2 * step + 1);
+    nvb = b.vh + v_tile(cv.tt, lb);
     if (BK_ABLATE & 4096) { nva = b.vh + v_tile(wk.t, 0); nvb = nva; }   // (experiment, wrong results: V fragments always from one hot tile)
   };
   v_next(1);
@@ -1267,15 +1198,15 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
 #pragma unroll
       for (int it = 0; it < 4; ++it)
         acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va[dt], pa[it], acc[dt][it], 0, 0, 0);
-      if constexpr (kMode != 2) {
+#endif
+#if !(BK_ABLATE & 2)
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
-          acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[dt], pb[it], acc[dt][it], 0, 0, 0);
-      }
+      for (int it = 0; it < 4; ++it)
+        acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[dt], pb[it], acc[dt][it], 0, 0, 0);
 #endif
 #if !(BK_ABLATE & 1)
       va[dt] = *reinterpret_cast<const half8*>(nva + dt * 1024);
-      if constexpr (kMode != 2) vb[dt] = *reinterpret_cast<const half8*>(nvb + dt * 1024);
+      vb[dt] = *reinterpret_cast<const half8*>(nvb + dt * 1024);
 #endif
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1341,7 +1272,7 @@ constexpr float kStaticBytesPerUs = BK_STATIC_BPUS;             // what one stre
 #define BK_STATIC_BPUS_F16 50.0e3f                              // fp16 mode: fewer set aside (measured 25 / 35 / 50 / 70 / 100e3: 69.2 / 69.7 / 65.7 / 67.3 / 68.7 us)
 #endif
 constexpr float kStaticBytesPerUsF16 = BK_STATIC_BPUS_F16;
-constexpr float kTileUs = 1.75f, kTileUsF16 = 0.55f, kTileUsMixed = 0.70f, kLaunchUs = 12.0f;   // tile step / fixed part of a compute workgroup (same estimate)
+constexpr float kTileUs = 1.75f, kTileUsF16 = 0.55f, kLaunchUs = 12.0f;   // tile step / fixed part of a compute workgroup (same estimate)
 static_assert(kSplitMax * kQT * 4 <= 2 * kPbuf, "merge weights live in the P buffers");
 static_assert(kConsumers * 16 * 65 * 4 + 2 * 4 * kQT * 4 <= 8 * kKbuf, "epilogue scratch lives in the K ring");
 
@@ -1447,7 +1378,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     int target = a.target;
     if (!(BK_ABLATE & 256)) {
       const float static_bytes = (float)ng * (float)hw * (float)kDo * 4.0f * 2.5f;
-      const float compute_us = kLaunchUs + (kTerms == 1 || kTerms == 4 ? kTileUsF16 : kTerms == 2 ? kTileUsMixed : kTileUs) * (float)W / (float)a.target;
+      const float compute_us = kLaunchUs + (kTerms != 3 ? kTileUsF16 : kTileUs) * (float)W / (float)a.target;
       int aside = (int)(static_bytes / (compute_us * (kTerms != 3 ? kStaticBytesPerUsF16 : kStaticBytesPerUs)) + 0.5f);
       aside = min(aside, a.target / 4);
       target = a.target - aside;
@@ -1457,7 +1388,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     // overlap): this search sits on the critical path of every workgroup, and one candidate at a time with shuffle
     // reductions cost 0.45 us per step, 3 us at the bench launch (r04 time line).
     constexpr int kSC = seg_cost_of(kTerms);
-    constexpr int kCq = kTerms == 1 || kTerms == 4 ? 2 : 1;   // (fp16 modes: a step is two tiles, an odd chunk wastes half of one)
+    constexpr int kCq = kTerms != 3 ? 2 : 1;              // (fp16 modes: a step is two tiles, an odd chunk wastes half of one)
     auto next_c = [](int c) { return c + (1 + (c >> 5) + kCq - 1) / kCq * kCq; };
     // chunks of this lane's object at chunk length c = bank_chunks(nqt, njt, c, kSC).nch with the two integer divisions done in
     // fp32 (all operands < 2^22: the quotient is off by at most one, fixed up) -- ~15 instructions instead of ~80
@@ -1589,12 +1520,11 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
 #if BK_CLK
     if (tid == 0 && clk_rec[5] == 0) clk_rec[5] = (long long)__builtin_amdgcn_s_memrealtime() - t_real;   // first segment starts
 #endif
-    if constexpr (kTerms != 3) {          // 1: fp16 operands, 4: the same with an exact query, 2: mixed (S in three terms, PV in one) -- one pipeline
-      constexpr int kMode = kTerms == 4 ? 3 : kTerms;
+    if constexpr (kTerms != 3) {          // 1: fp16 operands, 2: the same with an exact query -- one pipeline
       if (producer)
-        producer_loop_f16<kMode>(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, ln, t_entry, m_seg, l_seg);
+        producer_loop_f16<kTerms == 2>(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, ln, t_entry, m_seg, l_seg);
       else
-        consumer_loop_f16<kMode>(a, wk, Kl_, Pl_, Al, tpre, wave, ln, t_entry, acc);
+        consumer_loop_f16(a, wk, Kl_, Pl_, Al, tpre, wave, ln, t_entry, acc);
     } else {
       if (producer)
         producer_loop(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, ln, t_entry, m_seg, l_seg);
@@ -2178,7 +2108,7 @@ int launch_bank_append(void* bank, int no, int Tcap, int h, int w, int slot, con
 
 int launch_bank_stage(void* bank, int no, int Tcap, int h, int w, int slot0, int nf, const float* k4,
                       const float* v4, long long k_cs, long long k_os, long long v_cs, long long v_os,
-                      const int32_t* rects, hipStream_t st, const int32_t* slot_dev) {
+                      const int32_t* rects, hipStream_t st, const int32_t* slot_dev, bool colsum) {
   if (!bank || !k4 || !v4 || no <= 0 || Tcap <= 0 || h <= 0 || w <= 0 || nf <= 0 || slot0 < 0 ||
       slot0 + nf > Tcap)
     return RMNET_E_INVALID_ARG;
@@ -2187,6 +2117,9 @@ int launch_bank_stage(void* bank, int no, int Tcap, int h, int w, int slot0, int
   hipLaunchKernelGGL(bk_append, dim3(b.hwp / kJT, no * nf, 1 + kDo / kDe), dim3(kThreads), 0, st, b, slot0, slot_dev, nf,
                      k4, v4, k_cs, k_os, v_cs, v_os, rects);
   if (int e = check_launch()) return e;
+  // the slots' column sums feed the read-out of query cells OUTSIDE the query box (and of objects without a memory cell): a dense
+  // read (the drop-in entry without rectangles) has neither and skips the launch
+  if (!colsum) return RMNET_OK;
   hipLaunchKernelGGL(bk_colsum, dim3(no * nf), dim3(kDo), 0, st, b, slot0, slot_dev, nf);
   return check_launch();
 }
@@ -2231,8 +2164,6 @@ int launch_bank_main(const BankReadArgs& m, hipStream_t st) {
       hipLaunchKernelGGL(bk_main<1>, dim3(a.target), dim3(kRThreads), 0, st, a);
     else if (m.f16 == 2)
       hipLaunchKernelGGL(bk_main<2>, dim3(a.target), dim3(kRThreads), 0, st, a);
-    else if (m.f16 == 4)
-      hipLaunchKernelGGL(bk_main<4>, dim3(a.target), dim3(kRThreads), 0, st, a);
     else
       hipLaunchKernelGGL(bk_main<3>, dim3(a.target), dim3(kRThreads), 0, st, a);
     if (int e = check_launch()) return e;

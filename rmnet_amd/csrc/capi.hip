@@ -52,6 +52,7 @@ int rmnet_memory_read_f32_ev(const float* m_key, const float* m_val, const float
                              float* p_out, const int32_t* mem_rects, const int32_t* qry_rects,
                              int flags, void* workspace, size_t workspace_bytes, void* stream,
                              void* ev_start, void* ev_mid, void* ev_end) {
+  if ((flags & RMNET_MR_F16) && (flags & RMNET_MR_QX)) return RMNET_E_INVALID_ARG;   // one arithmetic per call
   MemReadArgs a;
   a.mk = m_key; a.mv = m_val; a.qk = q_key; a.qv = q_val;
   a.out = mem_val; a.p_out = p_out;
@@ -132,9 +133,9 @@ int rmnet_bank_read_f32_at(void* bank, int no, int Tcap, int h, int w, int T, co
                            void* workspace, size_t workspace_bytes, void* stream, void* ev_start, void* ev_mid,
                            void* ev_end) {
   BankReadArgs a;
-  if (flags != 0 && flags != RMNET_BANK_F16 && flags != RMNET_BANK_MIXED && flags != RMNET_BANK_QX) return RMNET_E_INVALID_ARG;
+  if (flags != 0 && flags != RMNET_BANK_F16 && flags != RMNET_BANK_QX) return RMNET_E_INVALID_ARG;
   a.bank = bank; a.no = no; a.Tcap = Tcap; a.h = h; a.w = w; a.T = T; a.T_dev = T_dev;
-  a.f16 = (flags & RMNET_BANK_F16) ? 1 : (flags & RMNET_BANK_MIXED) ? 2 : (flags & RMNET_BANK_QX) ? 4 : 0;
+  a.f16 = (flags & RMNET_BANK_F16) ? 1 : (flags & RMNET_BANK_QX) ? 2 : 0;
   a.qk = q_key; a.qv = q_val; a.qry_rects = qry_rects; a.out = mem_val;
   a.ws_o = nullptr; a.ws_ml = nullptr; a.ws_plan = nullptr; a.slots = 0;
   a.ws = workspace; a.ws_bytes = workspace_bytes;

@@ -216,13 +216,9 @@ constexpr int kSegCost = RMNET_SEG_COST;
 #define RMNET_SEG_COST_F16 12   // fp16-operand mode: a tile costs a third, a segment's fixed part does not
 #endif
 constexpr int kSegCostF16 = RMNET_SEG_COST_F16;
-#ifndef RMNET_SEG_COST_MIXED
-#define RMNET_SEG_COST_MIXED 12   // mixed mode (S in three terms, PV in one): a tile costs about what it costs in the fp16-operand mode
-#endif
-constexpr int kSegCostMixed = RMNET_SEG_COST_MIXED;
-// kTerms = the arithmetic of a bank read: 3 = split fp16 (three MFMA terms everywhere), 1 = fp16 operands, 4 = fp16 operands with an exact
-// query (two terms for the logits), 2 = mixed (three terms for the logits, one for O = V P)
-__host__ __device__ constexpr int seg_cost_of(int kTerms) { return kTerms == 1 || kTerms == 4 ? kSegCostF16 : kTerms == 2 ? kSegCostMixed : kSegCost; }
+// kTerms = the arithmetic of a bank read: 3 = split fp16 (three MFMA terms everywhere), 1 = fp16 operands, 2 = fp16 operands with an
+// exact query (two terms for the logits, one for O = V P)
+__host__ __device__ constexpr int seg_cost_of(int kTerms) { return kTerms != 3 ? kSegCostF16 : kSegCost; }
 // Division of the launch plan's small non-negative integers (all < 2^22).  On the device hipcc expands an integer division by a
 // run-time divisor into ~35 instructions, and the plan + the chunk lookup of bk_main do a dozen of them on the critical path of
 // every workgroup; an fp32 reciprocal is off by at most one there, and the remainder fixes it up (exact, ~8 instructions).
@@ -316,8 +312,8 @@ struct BankReadArgs {
   hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_end = nullptr;
   int gate = 0;               // != 0: bk_main returns at once when the bank's overflow word is set
   const int32_t* T_dev = nullptr;   // optional device-resident frame counter added to T
-  int f16 = 0;                // arithmetic: 0 split fp16 (three MFMA terms), 1 fp16 operands (hi planes only, one term), 2 mixed
-                              // (the logits S in three terms, O = V P in one: RMNET_BANK_MIXED), 4 fp16 operands + exact query (RMNET_BANK_QX)
+  int f16 = 0;                // arithmetic: 0 split fp16 (three MFMA terms), 1 fp16 operands (hi planes only, one term),
+                              // 2 fp16 operands with an exact query (RMNET_BANK_QX)
   int t0 = 0;                 // first slot read (chunked reads of a bank longer than one launch can take)
   float* ml_out = nullptr;    // optional [no][2][h*w]: soft-max state of the merged query cells (bank.hip: bk_chain)
 };
@@ -331,7 +327,7 @@ int launch_bank_append(void* bank, int no, int Tcap, int h, int w, int slot, con
                        const float* v4, const int32_t* rects, hipStream_t st, const int32_t* slot_dev = nullptr);
 int launch_bank_stage(void* bank, int no, int Tcap, int h, int w, int slot0, int nf, const float* k4,
                       const float* v4, long long k_cs, long long k_os, long long v_cs, long long v_os,
-                      const int32_t* rects, hipStream_t st, const int32_t* slot_dev = nullptr);   // nf frames of a strided [no,C,T,h,w] source
+                      const int32_t* rects, hipStream_t st, const int32_t* slot_dev = nullptr, bool colsum = true);   // nf frames of a strided [no,C,T,h,w] source
 size_t bank_overflow_offset(int no, int Tcap, int h, int w);
 int launch_bank_main(const BankReadArgs& a, hipStream_t st);   // bank.hip: the whole read (one launch per 64 objects)
 size_t bank_read_ws_bytes(int no, int h, int w);

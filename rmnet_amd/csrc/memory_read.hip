@@ -822,7 +822,7 @@ int launch_memory_read(const MemReadArgs& m, hipStream_t st) {
       // control block of the transient bank: the overflow word and the pairs' arrival tickets (the workspace is arbitrary memory)
       if (int e = launch_bank_ctl_clear(b.ovf, (int)(bank_ctl_bytes(m.no, m.h, m.w) / 4), st)) return e;
       if (int e = launch_bank_stage(bank, m.no, m.T, m.h, m.w, 0, m.T, m.mk, m.mv, mk_cs, mk_os, mv_cs, mv_os,
-                                    m.mem_rects, st))
+                                    m.mem_rects, st, nullptr, /*colsum=*/regional))
         return e;
       a.gate = b.ovf;
     }
@@ -836,7 +836,7 @@ int launch_memory_read(const MemReadArgs& m, hipStream_t st) {
       r.qk = m.qk; r.qv = m.qv; r.qry_rects = m.qry_rects; r.out = m.out;
       r.ws_o = a.ws_o; r.ws_ml = a.ws_ml; r.ws_plan = a.ws_plan; r.slots = (int)nslots;
       r.ws = nullptr; r.ws_bytes = 0; r.gate = 1;
-      r.f16 = (m.flags & RMNET_MR_F16) ? 1 : (m.flags & RMNET_MR_MIXED) ? 2 : (m.flags & RMNET_MR_QX) ? 4 : 0;
+      r.f16 = (m.flags & RMNET_MR_F16) ? 1 : (m.flags & RMNET_MR_QX) ? 2 : 0;
       if (int e = launch_bank_main(r, st)) return e;
     }
     // (mr_main plans its own ceil(M / 32) compacted tiles from the rectangles: the transient bank's per-frame tile

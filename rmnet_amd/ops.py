@@ -169,28 +169,25 @@ def memory_read(m_key, m_val, q_key, q_val, mem_rects=None, qry_rects=None, want
 
 BANK_F16 = 4                      # include/rmnet_hip.h: RMNET_BANK_F16 (== RMNET_MR_F16)
 MR_F16 = 4
-BANK_MIXED = 8                    # RMNET_BANK_MIXED (== RMNET_MR_MIXED)
-MR_MIXED = 8
-BANK_QX = 16                      # RMNET_BANK_QX (== RMNET_MR_QX)
-MR_QX = 16
-_PRECISION_FLAGS = {'split': 0, 'f16': BANK_F16, 'mixed': BANK_MIXED, 'qx': BANK_QX}
+BANK_QX = 8                       # RMNET_BANK_QX (== RMNET_MR_QX)
+MR_QX = 8
+_PRECISION_FLAGS = {'split': 0, 'f16': BANK_F16, 'qx': BANK_QX}
 
 
 def _precision(p):
     """'split': K, V, q and P enter the MFMAs as fp16 hi/lo pairs, three terms, fp32-class accuracy (default).
-    'mixed': the logits K^T q in those three terms, the soft-max weights and V rounded to fp16 for V P (one term).
     'f16': hi planes only -- fp16 operands, fp32 accumulate, about 2^-11 relative (include/rmnet_hip.h).
     'qx': 'f16' with the query as a hi/lo pair (its rounding is the logit error that does not average out)."""
     if p not in _PRECISION_FLAGS:
-        raise ValueError("precision must be 'split', 'mixed', 'qx' or 'f16'")
+        raise ValueError("precision must be 'split', 'qx' or 'f16'")
     return p
 
 
 def _loop_precision(p):
-    """Arithmetic of the frame loop's bank read: 'auto' (default), 'split', 'mixed' or 'f16' -- see RMNet.__init__ and
+    """Arithmetic of the frame loop's bank read: 'auto' (default), 'split', 'qx' or 'f16' -- see RMNet.__init__ and
     profiles/r05_iou_calibration.md for what 'auto' picks and why."""
-    if p not in ('auto', 'split', 'mixed', 'qx', 'f16'):
-        raise ValueError("read_precision must be 'auto', 'split', 'mixed', 'qx' or 'f16'")
+    if p not in ('auto', 'split', 'qx', 'f16'):
+        raise ValueError("read_precision must be 'auto', 'split', 'qx' or 'f16'")
     return p
 
 
@@ -203,7 +200,7 @@ class MemoryBank:
         lib = _lib.load()
         self.no, self.capacity, self.h, self.w = int(no), int(capacity), int(h), int(w)
         self.device = torch.device(device)
-        self.precision = _precision(precision)        # arithmetic of ``read``: 'split' (fp32-class, default), 'mixed' or 'f16'
+        self.precision = _precision(precision)        # arithmetic of ``read``: 'split' (fp32-class, default), 'qx' or 'f16'
         nb = lib.rmnet_bank_bytes(self.no, self.capacity, self.h, self.w)
         if nb == 0:
             raise RuntimeError('invalid bank geometry')

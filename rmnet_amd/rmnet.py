@@ -49,7 +49,7 @@ class MemoryReader(nn.Module):
     def __init__(self, return_affinity=False, precision='split'):
         super().__init__()
         self.return_affinity = return_affinity
-        self.precision = ops._precision(precision)     # 'mixed' / 'f16': see ops._precision (ops.MR_MIXED, ops.MR_F16)
+        self.precision = ops._precision(precision)     # 'qx' / 'f16': see ops._precision (ops.MR_QX, ops.MR_F16)
 
     def forward(self, m_key, m_val, q_key, q_val, mem_rects=None, qry_rects=None, T=None):
         return ops.memory_read(m_key.contiguous(), m_val.contiguous(), q_key.contiguous(),
@@ -68,13 +68,19 @@ class RMNet(nn.Module):
         super().__init__()
         self.cfg = cfg
         # arithmetic of the bank read in the frame loop:
-        #   'f16'   = fp16 operands, fp32 accumulate, ~2^-11 relative per read-out, 1.5-2x as fast;
         #   'split' = fp16 hi/lo pairs, three MFMA terms, fp32-class accuracy (1e-7) -- what rounds 1-3 ran everywhere;
-        #   'auto' (default since round 4) = 'f16' for clips with ONE object, 'split' for clips with several.
-        # The task's bar is mask IoU within 1e-3 of the CPU path.  Calibrated against that path (profiles/r04_iou_calibration.md,
-        # tests/test_gpu_parity.py) on procedural random weights: with one object per clip the fp16-operand loop gives IoU 1.0000
-        # (20-frame and 67-frame clips); with three objects 0.9991-0.9995; with five 0.9986-0.9992, i.e. not reliably inside the
-        # bar (the exact-fp32 GPU loop itself: >= 0.9997) -- the soft aggregation over several objects amplifies the read's 2^-11.
+        #   'f16'   = fp16 operands (K, q, P, V rounded to 11 bits), fp32 accumulate, 1.7x as fast;
+        #   'qx'    = 'f16' with the QUERY as a hi/lo pair (two terms for the logits): the rounding of q shifts all logits of a
+        #             query coherently and is most of what 'f16' costs on whole clips; 3 % slower than 'f16' in the frame loop;
+        #   'auto' (default) = 'f16' for clips with ONE object, 'qx' for clips with several.
+        # The task's bar is mask IoU within 1e-3 of the CPU path.  Calibrated against that path on the GPU
+        # (profiles/r05_iou_calibration.md; asserted by tests/test_gpu_parity.py) with the procedural random weights:
+        #   * one object, on clips whose masks HAVE a boundary (tests/live_fixture.py: foreground 20-35 % of the frame, 1-10 % of
+        #     the pixels within 0.1 of the threshold; a read-out noised by 1 % FAILS the same comparison): 'f16' 0.99993-0.99997,
+        #     foreground logits within 1.3e-3 (an IoU loss of 1e-3 corresponds to ~2e-2); 'qx' and 'split' 0.99999-1.00000, logits
+        #     within 1e-4 -- the exact-fp32 GPU loop's own distance from the CPU path (MIOpen vs CPU convolutions);
+        #   * three / five objects (20-30 frame clips): exact fp32 0.9997-1.0000, 'qx' 0.9993-0.9997, 'f16' 0.9986-0.9995: with
+        #     several objects the soft aggregation amplifies the read's error and 'f16' is not reliably inside the bar.
         self.read_precision = ops._loop_precision(read_precision)
         self.encoder_memory = EncoderMemory()
         self.encoder_query = EncoderQuery()
@@ -317,7 +323,7 @@ class RMNet(nn.Module):
         """The arithmetic ``read_precision`` stands for on clips with ``n_objects`` objects each ('auto': see __init__)."""
         if self.read_precision != 'auto':
             return self.read_precision
-        return 'f16' if all(int(n) <= 1 for n in n_objects) else 'split'
+        return 'f16' if all(int(n) <= 1 for n in n_objects) else 'qx'
 
     @torch.no_grad()
     def frame_step(self, ctx, bank, prev_frame, prev_mask, cur_frame, cur_flow, commit):

@@ -176,9 +176,8 @@ int main() {
     for (int t : targets) {
       check_launch(l.first, l.second, t, kSegCost, 1);
       check_launch(l.first, l.second, t, kSegCostF16, 2);
-      check_launch(l.first, l.second, t, kSegCostMixed, 1);   // mixed mode: the fp16 mode's segment cost, one-tile steps
     }
   if (fails) { std::printf("plan_check: %d failures\n", fails); return 1; }
-  std::printf("plan_check ok: %zu launches x %zu targets x 3 modes\n", launches.size(), sizeof(targets) / sizeof(targets[0]));
+  std::printf("plan_check ok: %zu launches x %zu targets x 2 modes\n", launches.size(), sizeof(targets) / sizeof(targets[0]));
   return 0;
 }

@@ -96,7 +96,7 @@ def test_flag_constants_of_the_python_mirror_match_the_header():
         RMNet(None, read_precision='fp8')
     net = RMNet(None)
     assert net.read_precision == 'auto' and MemoryReader().precision == 'split'      # the stand-alone reader: fp32-class unless asked
-    assert net.resolve_read_precision([1, 1, 1]) == 'f16' and net.resolve_read_precision([1, 3]) == 'split'   # calibrated per-clip choice
+    assert net.resolve_read_precision([1, 1, 1]) == 'f16' and net.resolve_read_precision([1, 3]) == 'qx'   # calibrated per-clip choice (profiles/r05_iou_calibration.md)
     assert RMNet(None, read_precision='f16').resolve_read_precision([5]) == 'f16'
     lib = _lib.load()
     # the fp16 switch is the only flag rmnet_bank_read_f32_at knows: anything else is refused before any launch
