@@ -7,7 +7,7 @@ import numpy as np, torch
 from rmnet_amd import ops
 from oracle import oracle
 # RMNET_BANK_PRECISION=f16 runs the fp16-operand mode: its bar is 2^-10 of the largest value (tests/test_gpu_parity.py)
-ATOL = 5e-3 if os.environ.get('RMNET_BANK_PRECISION') == 'f16' else 3e-5
+ATOL = 5e-3 if os.environ.get('RMNET_BANK_PRECISION') in ('f16', 'qx') else 3e-5
 dev = torch.device('cuda', 0)
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)

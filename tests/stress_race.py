@@ -8,7 +8,7 @@ import numpy as np, torch
 from rmnet_amd import ops
 from oracle import oracle
 # RMNET_BANK_PRECISION=f16 runs the fp16-operand mode: its bar is 2^-10 of the largest value (tests/test_gpu_parity.py)
-ATOL = 5e-3 if os.environ.get('RMNET_BANK_PRECISION') == 'f16' else 3e-5
+ATOL = 5e-3 if os.environ.get('RMNET_BANK_PRECISION') in ('f16', 'qx') else 3e-5
 dev = torch.device('cuda', 0)
 reads = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
