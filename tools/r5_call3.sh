@@ -20,4 +20,8 @@ for v in base r4tail; do
   RMNET_HIP_LIB=$lib RMNET_BANK_PRECISION=qx timeout 600 python tools/loop_clk.py 16 2>/dev/null | grep "in-loop" | sed "s/^/$v: /" >> $O/loop.txt
 done
 RMNET_HIP_LIB=build/variants/lib_clk.so RMNET_BANK_PRECISION=f16 timeout 600 python tools/loop_clk.py 16 2>/dev/null > $O/loop_clk_f16.txt
+for v in base pf4 pf12; do
+  lib=build/variants/lib_$v.so; [ $v = base ] && lib=rmnet_amd/librmnet_hip.so
+  RMNET_HIP_LIB=$lib timeout 900 python tools/kernel_rows.py 2>/dev/null > $O/kernel_rows_$v.json
+done
 tail -3 $O/pytest.txt; cat $O/stress.txt; sort $O/loop.txt
