@@ -362,12 +362,6 @@ constexpr int kRThreads = 64 * (kProducers + kConsumers);  // 768 = 12 waves = 3
 #ifndef BK_OUT_AUX
 #define BK_OUT_AUX 0   // cache policy of the stores to `out` (buffer aux bits: 2 = nt, 16 = sc1 write-through)
 #endif
-#ifndef BK_EARLY_TICKET
-#define BK_EARLY_TICKET 1  // experiments only: 0 = the arrival ticket is drawn after the walk (round 4)
-#endif
-#ifndef BK_EARLY_PEEK
-#define BK_EARLY_PEEK 1    // experiments only: 0 = the static queue is looked at after the epilogue only (round 4)
-#endif
 #ifndef BK_PLAN_NOEQ
 #define BK_PLAN_NOEQ 0 // experiments only: 1 = never take the equalised plan (A/B of the round-5 plan change)
 #endif
@@ -456,7 +450,7 @@ __device__ inline void query_range_check(const BankView& b, const half8 (&qh)[4]
 // producer wave the matrix pipe and the VALU overlap instead of running one after the other.
 __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
                                      const int* tpre, const int* tarea, int wave, int lane, long long t_entry,
-                                     float& m_out, float& l_out, int* arrive, int& ticket) {
+                                     float& m_out, float& l_out) {
   const BankView& b = a.b;
   const int o = wk.o;
   const int l15 = lane & 15, g = lane >> 4;
@@ -651,8 +645,6 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
   int kslot = 3;                                     // ring slot of tile n+3
   for (int n = 0; n < ntl; ++n) {
     BK_STAMP();   // loop top
-    if (BK_EARLY_TICKET && arrive && n == ntl - 1 && wave == 0 && lane == 0)   // the arrival ticket, one tile before the end (see producer_loop_f16)
-      ticket = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!(BK_ABLATE & 4)) {
       const int l1 = cs.seek(jt0 + n + 1);
       const int nvalid = n + 1 < ntl ? tarea[cs.tt] - l1 * kJT : 0;
@@ -881,7 +873,7 @@ struct L2Prefetch {
 template <bool kQx>
 __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
                                          const int* tpre, const int* tarea, int wave, int lane, long long t_entry,
-                                         float& m_out, float& l_out, int* arrive, int& ticket) {
+                                         float& m_out, float& l_out) {
   const BankView& b = a.b;
   const int o = wk.o;
   const int l15 = lane & 15, g = lane >> 4;
@@ -1044,11 +1036,6 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
   int pbuf = 2;                                      // (n + 2) % 3
   for (int n = 0; n < nst; ++n) {
     BK_STAMP();   // loop top
-    // the segment's arrival ticket (segment epilogue) is drawn at the top of the LAST step: its round trip (~1 us, a returning
-    // atomic) then hides under the step instead of standing between the walk and the publish / merge.  The merge protocol only
-    // needs "whoever holds a ticket finishes without waiting for anybody": true one step before the end as well.
-    if (BK_EARLY_TICKET && arrive && n == nst - 1 && wave == 0 && lane == 0)
-      ticket = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     mask_ragged(sp, nva, nvb);
     __builtin_amdgcn_sched_barrier(0);
     BK_STAMP();   // (head)
@@ -1462,7 +1449,6 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     pr[8] = a.slot0 + o_sb[og]; pr[9] = C; pr[10] = 0; pr[11] = 1;
   }
 
-  int q_peek = -1;                                 // (thread 0) the static queue's head as seen at the end of the last walk
   // =========================================== compute: this workgroup's chunk ===========================================
   auto compute = [&]() {
   int c;
@@ -1531,31 +1517,23 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
                                    // arithmetic of the loops below out of the segment loop (it then spills)
     f32x4 acc[kCDT][4];            // consumers: O of (64 channels x 64 queries)
     float m_seg = 0.0f, l_seg = 0.0f;   // producers: running reference (log2 domain) and sum of query 16 * wave + l15
-    // thread 0 draws the pair's arrival ticket inside the walk's last step (producer_loop_f16)
-    const int nsp_early = pair_slots(slot_obj, nqt, bc, wk.qt).count;
-    int* arrive_early = (BK_EARLY_TICKET && nsp_early > 1) ? b.cnt + 2 * ((size_t)wk.o * bank_nqt_max(hw) + wk.qt) : nullptr;
-    int ticket_early = -1;
 #if BK_CLK
     if (tid == 0 && clk_rec[5] == 0) clk_rec[5] = (long long)__builtin_amdgcn_s_memrealtime() - t_real;   // first segment starts
 #endif
     if constexpr (kTerms != 3) {          // 1: fp16 operands, 2: the same with an exact query -- one pipeline
       if (producer)
-        producer_loop_f16<kTerms == 2>(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, ln, t_entry, m_seg, l_seg, arrive_early, ticket_early);
+        producer_loop_f16<kTerms == 2>(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, ln, t_entry, m_seg, l_seg);
       else
         consumer_loop_f16(a, wk, Kl_, Pl_, Al, tpre, wave, ln, t_entry, acc);
     } else {
       if (producer)
-        producer_loop(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, ln, t_entry, m_seg, l_seg, arrive_early, ticket_early);
+        producer_loop(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, ln, t_entry, m_seg, l_seg);
       else
         consumer_loop(a, wk, Kl_, Pl_, Al, tpre, wave, ln, t_entry, acc);
     }
 #if BK_CLK
     if (tid == kRThreads - 1) clk_rec[6] = (long long)__builtin_amdgcn_s_memrealtime() - t_real;          // (last) tile loop over
 #endif
-    // a look at the static work queue NOW: by the end of a walk the set-aside workgroups have usually drained it, and the value only
-    // grows -- "drained" seen here is final.  Read after the epilogue instead, the same load queues behind the read-out stores of
-    // the whole chip and costs the workgroup 2.5-5.5 us before it may leave (r05 time line).
-    if (BK_EARLY_PEEK && tid == 0) q_peek = __hip_atomic_load(q_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // ================= segment epilogue (all 12 waves; every barrier below is reached by all of them) =================
 #if BK_TAIL == 1      // experiments: no epilogue at all (the accumulators are kept alive, nothing is stored)
@@ -1590,7 +1568,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     if (nsp > 1 && !(BK_ABLATE & 8)) {
       int* arrive = b.cnt + 2 * ((size_t)wk.o * bank_nqt_max(hw) + wk.qt);
       int* done = arrive + 1;
-      if (tid == 0) sflag = arrive_early ? ticket_early : __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) sflag = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();                                                              // E1: the ticket (and Msh / Lsh)
       const int ticket = sld(sflag);
       if (ticket != nsp - 1) {
@@ -2017,7 +1995,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     //  usually empty already, and 200 returning atomics on one word serialise at ~88 per microsecond -- the last workgroup left
     //  8 us after its epilogue without having served a ticket; loads of the same word do not queue up)
     if (tid == 0) {
-      const int h = q_peek >= ntickets ? q_peek : __hip_atomic_load(q_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int h = __hip_atomic_load(q_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       sflag = h >= ntickets ? h : __hip_atomic_fetch_add(q_head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
