@@ -299,7 +299,6 @@ struct BArgs {
   int32_t* ws_plan;          // [no][kPlanInts]
   int T;
   const int32_t* T_dev;      // optional: device-resident frame counter added to T (graph replay while the memory grows)
-  int trace_slot;            // BK_TRACE builds: the (unused) last partial slot receives the cycle stamps
   int gate;                  // != 0: do nothing when the bank's overflow word is set (mr_main then runs instead)
   int obj0, nobj;            // objects [obj0, obj0 + nobj) belong to this launch (nobj <= kMaxObj)
   int slot0, target;         // first partial slot of the launch; workgroups to aim for
@@ -322,52 +321,9 @@ constexpr int kProducers = 4;                              // waves 0-3
 constexpr int kConsumers = 8;                              // waves 4-11
 constexpr int kCDT = kDo / 16 / kConsumers;                // d-tiles (16 value channels) per consumer: 4
 constexpr int kRThreads = 64 * (kProducers + kConsumers);  // 768 = 12 waves = 3 per SIMD
-#ifndef BK_TRACE
-#define BK_TRACE 0     // experiments only: per-phase cycle stamps of block 0, waves 0 and 4
-#endif
-#ifndef BK_ABLATE
-#define BK_ABLATE 0    // experiments only, bit mask: 1 no V reloads, 2 no PV MFMAs, 4 no S/soft-max,
-#endif                 //                             8 no partial stores, 16 no K tile loads, 32 / 64 cheaper soft-max
-                       //                             (changes the control flow: not a clean ablation), 128 a barrier every 2nd tile
-                       //                             256 no static part (q_val half / masked cells), 1024 publish + ticket only (nobody merges),
-                       //                             2048 K / V tiles loaded on every SECOND tile only: the global-load traffic per flop of a
-                       //                             128-query workgroup, at this kernel's instruction stream (wrong results, timing only)
-#ifndef BK_TAIL
-#define BK_TAIL 0      // experiments only: 1 no segment epilogue (accumulators kept alive, nothing stored)
-#endif
-#ifndef BK_STATIC_ABL
-#define BK_STATIC_ABL 0   // experiments only: 1 static part without its stores, 2 without its q_val loads
-#endif
-#ifndef BK_PRIO
-#define BK_PRIO 2
-#endif
-#ifndef BK_SCHED
-#define BK_SCHED 1
-#endif
-#ifndef BK_YPRIO
-#define BK_YPRIO 0     // experiments only: static priority of the younger consumer waves (8-11)
-#endif
-#ifndef BK_VNT
-#define BK_VNT 0       // experiments only: non-temporal V fragment loads
-#endif
-#ifndef BK_F16_INTERLEAVE
-#define BK_F16_INTERLEAVE 6   // fp16 mode, producers: soft-max VALU instructions scheduled between two S MFMAs (0 = as the compiler likes)
-#endif
-#ifndef BK_PF
-#define BK_PF 7        // fp16 mode: L2 prefetch distance in steps (0 = off), see producer_loop_f16
-#endif
-#ifndef BK_PF_REM
-#define BK_PF_REM 0    // fp16 mode: remainder chunks prefetch all of their lines themselves (0 = they do not prefetch)
-#endif
-#ifndef BK_OUT_AUX
-#define BK_OUT_AUX 0   // cache policy of the stores to `out` (buffer aux bits: 2 = nt, 16 = sc1 write-through)
-#endif
-#ifndef BK_PLAN_NOEQ
-#define BK_PLAN_NOEQ 0 // experiments only: 1 = never take the equalised plan (A/B of the round-5 plan change)
-#endif
-#ifndef BK_CLK
-#define BK_CLK 0       // experiments only: per-workgroup shader-cycle / real-time stamps behind the plan records
-#endif
+constexpr int kProducerPrio = 2;   // static priority of the producer waves (s_setprio)
+constexpr int kSoftmaxInterleave = 6;   // fp16 modes, producers: soft-max VALU instructions scheduled between two S MFMAs
+constexpr int kPfSteps = 7;   // fp16 modes: L2 prefetch distance in steps of two tiles (L2Prefetch)
 
 // Workgroup = 12 waves (3 per SIMD), 64 compacted queries x one split of the tile list.
 //   waves 0-3  ("producers", static priority): S = K^T Q for 16 queries each (24 MFMAs per 32-cell
@@ -416,11 +372,6 @@ struct Cursor {
   }
 };
 
-#if BK_TRACE
-#define BK_STAMP() do { if (trace_on && trn < 1000) trc[trn++] = (long long)__builtin_readcyclecounter(); } while (0)
-#else
-#define BK_STAMP() do {} while (0)
-#endif
 
 // A q_key element of a query INSIDE the box whose scaled value leaves fp16's window (|x| * qscale >= 65504, i.e. |q_key| beyond
 // ~8e3), or a NaN / Inf, cannot be represented in the query fragments: it is counted in the bank's overflow word, like an
@@ -449,20 +400,13 @@ __device__ inline void query_range_check(const BankView& b, const half8 (&qh)[4]
 // The S MFMAs of tile n+2 and the soft-max VALU chain of tile n+1 are independent, so inside the
 // producer wave the matrix pipe and the VALU overlap instead of running one after the other.
 __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
-                                     const int* tpre, const int* tarea, int wave, int lane, long long t_entry,
+                                     const int* tpre, const int* tarea, int wave, int lane,
                                      float& m_out, float& l_out) {
   const BankView& b = a.b;
   const int o = wk.o;
   const int l15 = lane & 15, g = lane >> 4;
   const int jt0 = wk.jt0, ntl = wk.ntl;
-#if BK_TRACE
-  long long* trc = reinterpret_cast<long long*>(a.ws_o + (size_t)a.trace_slot * (size_t)kDo * kQT);
-  int trn = 0;
-  const bool trace_on = blockIdx.x == 0 && wave == 0 && lane == 0;
-  if (trace_on) trc[trn++] = t_entry;
-#endif
-  BK_STAMP();
-  // query fragments (B operand of S): lane (query l15, group g) holds channels 32ks + 8g + e
+    // query fragments (B operand of S): lane (query l15, group g) holds channels 32ks + 8g + e
   half8 qh[4], ql[4];
   {
     const int qn = wk.qt * kQT + wave * 16 + l15;
@@ -630,7 +574,7 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
   f32x4 sp0, sp1;                  // S of the tile after it (computed one iteration earlier)
   Frags f;
   __syncthreads();                                   // A: K tiles 0..3 in LDS
-  if (!(BK_ABLATE & 4)) {
+  {
     f32x4 s0, s1;
     k_frags(f, 0);
     s_mfma(f, s0, s1);
@@ -641,25 +585,19 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
     k_frags(f, 2);                                   // for the MFMAs of iteration 0
   }
   __syncthreads();                                   // B: P(0) visible
-  BK_STAMP();
-  int kslot = 3;                                     // ring slot of tile n+3
+    int kslot = 3;                                     // ring slot of tile n+3
   for (int n = 0; n < ntl; ++n) {
-    BK_STAMP();   // loop top
-    if (!(BK_ABLATE & 4)) {
+        {
       const int l1 = cs.seek(jt0 + n + 1);
       const int nvalid = n + 1 < ntl ? tarea[cs.tt] - l1 * kJT : 0;
       f32x4 s0, s1;
       s_mfma(f, s0, s1);                             // tile n+2 (fragments read before the barrier)
-#if BK_SCHED == 1
       __builtin_amdgcn_sched_barrier(0);             // MFMAs first (the pipe is idle right after a barrier)
-#endif
-      BK_STAMP();   // MFMAs issued
-
+      
       soft_max(sp0, sp1, nvalid, (n + 1) & 1);       // tile n+1
-      BK_STAMP();   // soft-max done
-      sp0 = s0; sp1 = s1;
+            sp0 = s0; sp1 = s1;
       k_frags(f, kslot);                             // tile n+3: its LDS latency hides under the barrier
-      if (!(BK_ABLATE & 16) && !((BK_ABLATE & 2048) && (n & 1))) {
+      {
         // K ring: tile n+4 (requested one iteration ago) -> slot n%4, whose last reader (tile n) passed
         // the barrier of iteration n-3; request tile n+5 (a clamped duplicate past the end: harmless)
         k_store(kr, (kslot + 1) & 3);
@@ -668,22 +606,16 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
       }
     }
     kslot = (kslot + 1) & 3;
-    BK_STAMP();   // S/soft-max done
-#if BK_ABLATE & 128
-    if (n & 1)    // (experiment, wrong results: a barrier every second tile only -- how much is the coupling worth?)
-#endif
-    __syncthreads();
-    BK_STAMP();   // after barrier
-  }
+        __syncthreads();
+      }
   m_out = mref * kSraw;                                // log2 domain; the segment's epilogue takes it from here
   l_out = lsum;
   query_range_check(b, qh, wk.qt * kQT + wave * 16 + l15 < wk.Mq);
-  BK_STAMP();
-}
+  }
 
 // ---------------------------------------------------------------- consumers: O += V P, K ring
 __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
-                                     const int* tpre, int wave, int lane, long long t_entry,
+                                     const int* tpre, int wave, int lane,
                                      f32x4 (&acc)[kCDT][4]) {
   const BankView& b = a.b;
   const int o = wk.o;
@@ -691,17 +623,7 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
   const int jt0 = wk.jt0, ntl = wk.ntl;
   const size_t so0 = (size_t)o * b.Tcap;
   const size_t tiles_per_slot = (size_t)(b.hwp / kJT);
-#if BK_TRACE
-  long long* trc = reinterpret_cast<long long*>(a.ws_o + (size_t)a.trace_slot * (size_t)kDo * kQT) + 1024;
-  int trn = 0;
-#ifndef BK_TRACE_WAVE
-#define BK_TRACE_WAVE kProducers
-#endif
-  const bool trace_on = blockIdx.x == 0 && wave == BK_TRACE_WAVE && lane == 0;
-  if (trace_on) trc[trn++] = t_entry;
-#endif
-  BK_STAMP();
-  // V: fragment-ordered planes; this wave's first d-tile and its lane inside a tile's 32 KB plane
+    // V: fragment-ordered planes; this wave's first d-tile and its lane inside a tile's 32 KB plane
   const int dt0 = kCDT * (wave - kProducers);
   const size_t vlane = (size_t)(dt0 * 64 + lane) * 16;
   auto v_tile = [&](int tt, int ll) { return ((so0 + tt) * tiles_per_slot + ll) * (size_t)(kDo * kJT * 2) + vlane; };
@@ -728,12 +650,10 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
     for (int it = 0; it < 4; ++it) acc[dt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();                                   // A: K tiles 0..3 visible
   __syncthreads();                                   // B: P(0) visible
-  BK_STAMP();
-
+  
   for (int n = 0; n < ntl; ++n) {
     const int buf = n & 1;
-    BK_STAMP();   // loop top
-    const char* pfr = Pl_ + buf * kPbuf;
+        const char* pfr = Pl_ + buf * kPbuf;
     const f32x4 al = *reinterpret_cast<const f32x4*>(Al + buf * kQT + l15 * 4);
     half8 bh[4], bl[4];                              // all P fragments of this tile
 #pragma unroll
@@ -751,14 +671,10 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
 #pragma unroll
         for (int it = 0; it < 4; ++it) acc[dt][it] *= al[it];
     }
-#if BK_TRACE > 1
-    BK_STAMP();   // head done (P fragments requested, K ring fed, cursors advanced)
-#endif
     // ---- O += V P: 4 channel tiles x 4 query tiles x 3 split terms; the 4 query tiles between two
     //      uses of an accumulator keep the MFMAs independent
 #pragma unroll
     for (int dt = 0; dt < kCDT; ++dt) {
-#if !(BK_ABLATE & 2)
 #pragma unroll
       for (int it = 0; it < 4; ++it)
         acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[dt], bh[it], acc[dt][it], 0, 0, 0);
@@ -768,41 +684,26 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
 #pragma unroll
       for (int it = 0; it < 4; ++it)
         acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[dt], bh[it], acc[dt][it], 0, 0, 0);
-#endif
-      if (!(BK_ABLATE & 1) && !((BK_ABLATE & 2048) && (n & 1))) {   // this channel tile's fragments of the next tile, unconditionally
-#if BK_VNT
-        vh[dt] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(nvh + dt * 1024));
-        vl[dt] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(nvl + dt * 1024));
-#else
+      {   // this channel tile's fragments of the next tile, unconditionally
         vh[dt] = *reinterpret_cast<const half8*>(nvh + dt * 1024);
         vl[dt] = *reinterpret_cast<const half8*>(nvl + dt * 1024);
-#endif
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE (the scheduler sinks them to the end)
-#if BK_TRACE > 1
-      BK_STAMP();   // channel tile done
-#endif
     }
-    BK_STAMP();   // PV done
-#if BK_ABLATE & 128
-    if (n & 1)
-#endif
-    __syncthreads();   // the one barrier per tile
-    BK_STAMP();   // after barrier
-  }
-  BK_STAMP();
-
+        __syncthreads();   // the one barrier per tile
+      }
+  
 }
 
 // ---- L2 prefetch of the fp16-operand walk.  Inside the frame loop nothing of the bank is in a cache when the read starts (the
 // convolutions between two reads stream hundreds of MB), a V fragment load is issued ONE step (~1.3 us) before its use and an
 // HBM miss under load takes longer than that: the tile walk then runs at memory latency, not at the matrix pipe's pace (measured
 // in the loop: 1.77 us per step against 1.30 with a warm cache).  The nqt workgroups of a column block walk the same K / V tiles
-// in lockstep on one XCD, i.e. behind one L2: each of them touches 1/nqt of the 128-byte lines of the step BK_PF steps ahead
+// in lockstep on one XCD, i.e. behind one L2: each of them touches 1/nqt of the 128-byte lines of the step kPfSteps steps ahead
 // (one dword per line) so that the demand loads of all of them hit the L2.  The touch is an LDS-DMA load into a 256-byte junk
 // patch of the issuing wave: no destination register, nothing ever waits for it (hipcc does not see the load: its own counted
 // waits only get more conservative; __syncthreads() stays a bare barrier).  In the loop the producers issue it (one wave
-// instruction per step for the usual 12 query tiles); the first BK_PF - 1 steps are touched by the CONSUMERS while they wait for
+// instruction per step for the usual 12 query tiles); the first kPfSteps - 1 steps are touched by the CONSUMERS while they wait for
 // the producers' first soft-max -- in the producers' own prologue those address computations sat on the critical path of the
 // whole workgroup.
 struct L2Prefetch {
@@ -872,21 +773,14 @@ struct L2Prefetch {
 // weighted sum): on whole clips it is most of what the fp16-operand read costs in mask IoU (profiles/r05_iou_calibration.md).
 template <bool kQx>
 __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
-                                         const int* tpre, const int* tarea, int wave, int lane, long long t_entry,
+                                         const int* tpre, const int* tarea, int wave, int lane,
                                          float& m_out, float& l_out) {
   const BankView& b = a.b;
   const int o = wk.o;
   const int l15 = lane & 15, g = lane >> 4;
   const int jt0 = wk.jt0, ntl = wk.ntl;
   const int nst = (ntl + 1) >> 1;                    // steps of two tiles (the last one may be half empty)
-#if BK_TRACE
-  long long* trc = reinterpret_cast<long long*>(a.ws_o + (size_t)a.trace_slot * (size_t)kDo * kQT);
-  int trn = 0;
-  const bool trace_on = blockIdx.x == 0 && wave == 0 && lane == 0;
-  if (trace_on) trc[trn++] = t_entry;
-#endif
-  BK_STAMP();
-  half8 qh[4], ql[kQx ? 4 : 1];
+    half8 qh[4], ql[kQx ? 4 : 1];
   {
     const int qn = wk.qt * kQT + wave * 16 + l15;
     const bool qvalid = qn < wk.Mq;
@@ -917,7 +811,7 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
   for (int e = 0; e < 8; ++e) ones[e] = (_Float16)1.0f;
 
   L2Prefetch pf;
-  if (BK_PF) pf.init(b, wk, tpre, Kl_, wave);
+  pf.init(b, wk, tpre, Kl_, wave);
 
   struct Frags { half8 a0[4], a1[4], b0[4], b1[4]; };   // tile A cells 0-15 / 16-31, tile B cells 0-15 / 16-31
   auto k_frags = [&](Frags& f, int kslot) {             // 16 conflict-free ds_read_b128 (XOR-swizzled rows)
@@ -1032,65 +926,43 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
   }
   __syncthreads();                                   // B: P(0), P(1) visible; ring slot 0 free
   __syncthreads();                                   // C: K step 4 in slot 0
-  BK_STAMP();
-  int pbuf = 2;                                      // (n + 2) % 3
+    int pbuf = 2;                                      // (n + 2) % 3
   for (int n = 0; n < nst; ++n) {
-    BK_STAMP();   // loop top
-    mask_ragged(sp, nva, nvb);
+        mask_ragged(sp, nva, nvb);
     __builtin_amdgcn_sched_barrier(0);
-    BK_STAMP();   // (head)
-    S4 s0;
-#if BK_ABLATE & 4
-    s0 = sp;
-#else
+        S4 s0;
     s_mfma(f, s0);                                   // step n+3
     soft_max(sp, pbuf);                              // step n+2
-#endif
     // one S MFMA, then a few soft-max VALU instructions, and so on: issued back to back the 16 MFMAs of this wave wait
     // for the pipe behind the consumers' (~40 cycles each, trace) while its VALU chain sits behind them in program order
-#if BK_F16_INTERLEAVE
 #pragma unroll
     for (int i = 0; i < (kQx ? 32 : 16); ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, kQx ? (BK_F16_INTERLEAVE + 1) / 2 : BK_F16_INTERLEAVE, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, kQx ? (kSoftmaxInterleave + 1) / 2 : kSoftmaxInterleave, 0);
     }
-#endif
     __builtin_amdgcn_sched_barrier(0);
-    BK_STAMP();   // S MFMAs + soft-max done
-    sp = s0;
-#if !(BK_ABLATE & 64)
+        sp = s0;
     k_frags(f, n & 3);                               // step n+4
-#endif
     step_valid(n + 3, nva, nvb);                     // (LDS round trips: they end under the barrier)
     pbuf = pbuf == 2 ? 0 : pbuf + 1;
-    if (BK_PF) pf.touch(n + BK_PF, wave, kProducers, lane);
-    BK_STAMP();   // K frags requested
-    __syncthreads();
-    BK_STAMP();   // after barrier
-  }
+    pf.touch(n + kPfSteps, wave, kProducers, lane);
+        __syncthreads();
+      }
   m_out = mref * kSraw;
   l_out = lsum;
   query_range_check(b, qh, wk.qt * kQT + wave * 16 + l15 < wk.Mq);
-  if (BK_PF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the patch is free again; the youngest touch is BK_PF steps old)
-  BK_STAMP();
-}
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the patch is free again; the youngest touch is kPfSteps steps old)
+  }
 
 __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
-                                         const int* tpre, int wave, int lane, long long t_entry,
+                                         const int* tpre, int wave, int lane,
                                          f32x4 (&acc)[kCDT][4]) {
   const BankView& b = a.b;
   const int o = wk.o;
   const int l15 = lane & 15;
   const int jt0 = wk.jt0, ntl = wk.ntl;
   const int nst = (ntl + 1) >> 1;
-#if BK_TRACE
-  long long* trc = reinterpret_cast<long long*>(a.ws_o + (size_t)a.trace_slot * (size_t)kDo * kQT) + 1024;
-  int trn = 0;
-  const bool trace_on = blockIdx.x == 0 && wave == BK_TRACE_WAVE && lane == 0;
-  if (trace_on) trc[trn++] = t_entry;
-#endif
-  BK_STAMP();
-  const size_t so0 = (size_t)o * b.Tcap;
+    const size_t so0 = (size_t)o * b.Tcap;
   const size_t tiles_per_slot = (size_t)(b.hwp / kJT);
   const int dt0 = kCDT * (wave - kProducers);
   const size_t vlane = (size_t)(dt0 * 64 + lane) * 16;
@@ -1157,19 +1029,18 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
     }
   };
   __syncthreads();                                   // A: K steps 0..3 in the ring
-  if (BK_PF) {                                       // (idle until B: the producers compute S(0..2), P(0), P(1))
+  {                                       // (idle until B: the producers compute S(0..2), P(0), P(1))
     L2Prefetch pf;
     pf.init(b, wk, tpre, Kl_, wave);
 #pragma unroll 1
-    for (int s_ = 1; s_ < BK_PF; ++s_) pf.touch(s_, wave - kProducers, kConsumers, lane);   // (step 0 and the K tiles of steps 1..4 are demand loads)
+    for (int s_ = 1; s_ < kPfSteps; ++s_) pf.touch(s_, wave - kProducers, kConsumers, lane);   // (step 0 and the K tiles of steps 1..4 are demand loads)
   }
   __syncthreads();                                   // B: P(0), P(1) visible; ring slot 0 free
   k_store(kr, 0);                                    // step 4
   k_load(kr, 5);
   p_frags(0);
   __syncthreads();                                   // C
-  BK_STAMP();
-  int pnext = 1;                                     // (n + 1) % 3
+    int pnext = 1;                                     // (n + 1) % 3
   // addresses of the NEXT step's V tiles: found before the barrier, so that an iteration starts with MFMAs
   const char *nva, *nvb;
   auto v_next = [&](int step) {
@@ -1177,15 +1048,11 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
     nva = b.vh + v_tile(cv.tt, la);
     const int lb = cv.seek(jt0 + 2 * step + 1);
     nvb = b.vh + v_tile(cv.tt, lb);
-    if (BK_ABLATE & 4096) { nva = b.vh + v_tile(wk.t, 0); nvb = nva; }   // (experiment, wrong results: V fragments always from one hot tile)
   };
   v_next(1);
   for (int n = 0; n < nst; ++n) {
-    BK_STAMP();   // loop top
-#if !(BK_ABLATE & 16)
-    k_store(kr, (n + 1) & 3);                        // step n+5 (its slot was last read in iteration n-3)
+        k_store(kr, (n + 1) & 3);                        // step n+5 (its slot was last read in iteration n-3)
     k_load(kr, n + 6);
-#endif
     if (__any(al[0] != 1.0f || al[1] != 1.0f || al[2] != 1.0f || al[3] != 1.0f)) {
 #pragma unroll
       for (int dt = 0; dt < kCDT; ++dt)
@@ -1194,34 +1061,22 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
     }
 #pragma unroll
     for (int dt = 0; dt < kCDT; ++dt) {
-#if !(BK_ABLATE & 2)
 #pragma unroll
       for (int it = 0; it < 4; ++it)
         acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va[dt], pa[it], acc[dt][it], 0, 0, 0);
-#endif
-#if !(BK_ABLATE & 2)
 #pragma unroll
       for (int it = 0; it < 4; ++it)
         acc[dt][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[dt], pb[it], acc[dt][it], 0, 0, 0);
-#endif
-#if !(BK_ABLATE & 1)
       va[dt] = *reinterpret_cast<const half8*>(nva + dt * 1024);
       vb[dt] = *reinterpret_cast<const half8*>(nvb + dt * 1024);
-#endif
       __builtin_amdgcn_sched_barrier(0);
     }
-#if BK_ABLATE & 32
-    if (n == 0)   // (experiment, wrong results: the P fragments are read once per segment)
-#endif
     p_frags(pnext);                                  // step n+1: published an iteration ago; lands under the barrier
     pnext = pnext == 2 ? 0 : pnext + 1;
     v_next(n + 2);
-    BK_STAMP();   // PV done
-    __syncthreads();
-    BK_STAMP();   // after barrier
+        __syncthreads();
+      }
   }
-  BK_STAMP();
-}
 
 constexpr int kMaxObj = kBankMaxObj;    // objects planned together in one launch (the launcher groups more)
 
@@ -1260,18 +1115,9 @@ __device__ inline float wave_sum_f(float v) {
 // drained by a few workgroups that get no chunk (the plan sets them aside, scaled to the launch) while the others
 // compute, and by every workgroup that has finished its segments -- among them the early arrivers of a pair, while
 // the pair's last arriver merges.
-#ifndef BK_STATIC_ROWS
-#define BK_STATIC_ROWS 2
-#endif
-constexpr int kStaticRowsPerTicket = BK_STATIC_ROWS;            // (object, channel) rows a wave takes per ticket
-#ifndef BK_STATIC_BPUS
-#define BK_STATIC_BPUS 35.0e3f
-#endif
-constexpr float kStaticBytesPerUs = BK_STATIC_BPUS;             // what one streaming workgroup moves (sizing of the set-aside)
-#ifndef BK_STATIC_BPUS_F16
-#define BK_STATIC_BPUS_F16 50.0e3f                              // fp16 mode: fewer set aside (measured 25 / 35 / 50 / 70 / 100e3: 69.2 / 69.7 / 65.7 / 67.3 / 68.7 us)
-#endif
-constexpr float kStaticBytesPerUsF16 = BK_STATIC_BPUS_F16;
+constexpr int kStaticRowsPerTicket = 2;            // (object, channel) rows a wave takes per ticket
+constexpr float kStaticBytesPerUs = 35.0e3f;             // what one streaming workgroup moves (sizing of the set-aside)
+constexpr float kStaticBytesPerUsF16 = 50.0e3f;
 constexpr float kTileUs = 1.75f, kTileUsF16 = 0.55f, kLaunchUs = 12.0f;   // tile step / fixed part of a compute workgroup (same estimate)
 static_assert(kSplitMax * kQT * 4 <= 2 * kPbuf, "merge weights live in the P buffers");
 static_assert(kConsumers * 16 * 65 * 4 + 2 * 4 * kQT * 4 <= 8 * kKbuf, "epilogue scratch lives in the K ring");
@@ -1303,20 +1149,13 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   int* tpre = reinterpret_cast<int*>(Al + 3 * kQT);
   int* tarea = tpre + kMaxT + 4;
 
-  const long long t_entry = (long long)__builtin_readcyclecounter();
-#if BK_CLK
-  const long long t_real = (long long)__builtin_amdgcn_s_memrealtime();
-#endif
   const BankView& b = a.b;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool producer = wave < kProducers;
   if (a.gate && __builtin_amdgcn_readfirstlane(*b.ovf) != 0) return;   // out-of-window element: exact fp32 path runs
   if (tid == 0) sgave = 0;                                              // (set by a merge that timed out; read after several barriers)
-  if (producer && BK_PRIO > 0) __builtin_amdgcn_s_setprio(BK_PRIO);
-#if BK_YPRIO
-  if (wave >= kProducers + kConsumers / 2) __builtin_amdgcn_s_setprio(BK_YPRIO);   // experiment: the younger consumer of each SIMD
-#endif
+  if (producer) __builtin_amdgcn_s_setprio(kProducerPrio);
   const int ng = a.nobj;
   const int hw = b.hw;
   // The frame count may live on the device (graph replay): its load, the areas of the first 64 slots and the query
@@ -1367,16 +1206,13 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     }
   }
   __syncthreads();
-#if BK_CLK
-  const long long t_loads = (long long)__builtin_amdgcn_s_memrealtime() - t_real;   // areas / rectangles in LDS
-#endif
   if (tid < RMNET_WAVE) {   // one wave, lane = object
     const int nqt = tid < ng ? o_nqt[tid] : 0, njt = tid < ng ? o_njt[tid] : 0;
     const int W = wave_sum_fast(nqt * njt), njt_max = wave_max_fast(njt);
     // workgroups set aside for the static part: what it takes to stream it in about the time the others compute
     // (the finishers drain whatever is left, so a wrong guess costs little either way)
     int target = a.target;
-    if (!(BK_ABLATE & 256)) {
+    {
       const float static_bytes = (float)ng * (float)hw * (float)kDo * 4.0f * 2.5f;
       const float compute_us = kLaunchUs + (kTerms != 3 ? kTileUsF16 : kTileUs) * (float)W / (float)a.target;
       int aside = (int)(static_bytes / (compute_us * (kTerms != 3 ? kStaticBytesPerUsF16 : kStaticBytesPerUs)) + 0.5f);
@@ -1424,7 +1260,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
       const int c1 = next_c(C0), c2 = next_c(c1);
       const int m0 = wave_sum_fast(neq_at(C0)), m1 = wave_sum_fast(neq_at(c1)), m2 = wave_sum_fast(neq_at(c2));
       const int ceq = m0 <= target ? C0 : m1 <= target ? c1 : (m2 <= target && kTerms != 3) ? c2 : 0;   // (split mode: a tile costs 3x, one candidate less)
-      if (ceq && !(BK_PLAN_NOEQ)) { C0 = ceq; blocks = 2; }
+      if (ceq) { C0 = ceq; blocks = 2; }
     }
     if (!blocks && wave_sum_fast(bank_chunks(nqt, njt, C0, kSC, 1).nch) <= target) blocks = 1;   // short objects as blocks of their own (common.h)
     const BankChunks bc0 = bank_chunks(nqt, njt, C0, kSC, blocks);
@@ -1436,10 +1272,6 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   __syncthreads();
   auto sld = [](const int& x) { return __builtin_amdgcn_readfirstlane(x); };   // LDS value -> SGPR
   const int nchunks = sld(plan_n), C = sld(plan_c);
-#if BK_CLK
-  long long* clk_rec = reinterpret_cast<long long*>(a.ws_plan + (size_t)(a.obj0 + a.nobj) * kPlanInts + 16) + 8 * blockIdx.x;
-  if (tid == 0) { clk_rec[4] = (long long)__builtin_amdgcn_s_memrealtime() - t_real; clk_rec[5] = 0; clk_rec[6] = 0; clk_rec[7] = t_loads; }   // plan done
-#endif
   if ((int)blockIdx.x < ng && tid == 0) {   // plan record of object blockIdx.x (tools / debugging only)
     const int og = blockIdx.x;
     int32_t* pr = a.ws_plan + (size_t)(a.obj0 + og) * kPlanInts;
@@ -1517,34 +1349,19 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
                                    // arithmetic of the loops below out of the segment loop (it then spills)
     f32x4 acc[kCDT][4];            // consumers: O of (64 channels x 64 queries)
     float m_seg = 0.0f, l_seg = 0.0f;   // producers: running reference (log2 domain) and sum of query 16 * wave + l15
-#if BK_CLK
-    if (tid == 0 && clk_rec[5] == 0) clk_rec[5] = (long long)__builtin_amdgcn_s_memrealtime() - t_real;   // first segment starts
-#endif
     if constexpr (kTerms != 3) {          // 1: fp16 operands, 2: the same with an exact query -- one pipeline
       if (producer)
-        producer_loop_f16<kTerms == 2>(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, ln, t_entry, m_seg, l_seg);
+        producer_loop_f16<kTerms == 2>(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, ln, m_seg, l_seg);
       else
-        consumer_loop_f16(a, wk, Kl_, Pl_, Al, tpre, wave, ln, t_entry, acc);
+        consumer_loop_f16(a, wk, Kl_, Pl_, Al, tpre, wave, ln, acc);
     } else {
       if (producer)
-        producer_loop(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, ln, t_entry, m_seg, l_seg);
+        producer_loop(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, ln, m_seg, l_seg);
       else
-        consumer_loop(a, wk, Kl_, Pl_, Al, tpre, wave, ln, t_entry, acc);
+        consumer_loop(a, wk, Kl_, Pl_, Al, tpre, wave, ln, acc);
     }
-#if BK_CLK
-    if (tid == kRThreads - 1) clk_rec[6] = (long long)__builtin_amdgcn_s_memrealtime() - t_real;          // (last) tile loop over
-#endif
 
     // ================= segment epilogue (all 12 waves; every barrier below is reached by all of them) =================
-#if BK_TAIL == 1      // experiments: no epilogue at all (the accumulators are kept alive, nothing is stored)
-    if (!producer) {
-#pragma unroll
-      for (int dt = 0; dt < kCDT; ++dt)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) asm volatile("" :: "v"(acc[dt][it]));
-    }
-    return;
-#endif
     const int l15 = ln & 15, g = ln >> 4;
     const PairSlots ps = pair_slots(slot_obj, nqt, bc, wk.qt);
     const int nsp = ps.count;
@@ -1565,7 +1382,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
                                                (int)(kSlotF * 4), 0x00020000);
     };
     if (producer && g == 0) { Msh[wave * 16 + l15] = m_seg; Lsh[wave * 16 + l15] = l_seg; }
-    if (nsp > 1 && !(BK_ABLATE & 8)) {
+    if (nsp > 1) {
       int* arrive = b.cnt + 2 * ((size_t)wk.o * bank_nqt_max(hw) + wk.qt);
       int* done = arrive + 1;
       if (tid == 0) sflag = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1610,7 +1427,6 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
           __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
-      if (BK_ABLATE & 1024) return;
       __syncthreads();                                                              // E2: all partials of the pair are in memory
     } else {
       __syncthreads();                                                              // (Msh / Lsh visible)
@@ -1751,14 +1567,6 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
         cell = (wk.qr.cy0 + ry) * b.w + wk.qr.cx0 + (nq - ry * rw);
       }
       float* __restrict__ outo = a.out + (size_t)wk.o * 2 * kDo * hw + cell;
-#if BK_OUT_AUX
-      const __amdgpu_buffer_rsrc_t rs_out = [&]() {       // the read-out half of this object's output (wave-uniform base)
-        float* base = a.out + (size_t)wk.o * 2 * kDo * hw;
-        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(base));
-        const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(base) >> 32));
-        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((uintptr_t)bhi << 32) | blo), 0, kDo * hw * 4, 0x00020000);
-      }();
-#endif
 #pragma unroll
       for (int dt = 0; dt < kCDT; ++dt) {
 #pragma unroll
@@ -1769,11 +1577,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
 #pragma unroll
         for (int ch = 0; ch < 16; ++ch) {
           const float x = T[ch * 65 + ln];
-#if BK_OUT_AUX
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rs_out, qvalid ? ((16 * (dt0 + dt) + ch) * hw + cell) * 4 : 0x40000000, 0, BK_OUT_AUX);
-#else
           if (qvalid) outo[(size_t)(16 * (dt0 + dt) + ch) * hw] = x;
-#endif
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -1800,7 +1604,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     wk.jt0 = bc.nfull * bc.Cb + j0;
     wk.ntl = j1 - j0;
     wk.slot = slot_obj + nqt * bc.nfull + cr + qt;
-    wk.pf_part = 0; wk.pf_nparts = BK_PF_REM ? 1 : 0;
+    wk.pf_part = 0; wk.pf_nparts = 0;          // (remainder chunks do not prefetch: alone they would touch every line of a step)
     if (!first) __syncthreads();      // the previous segment's LDS (K ring, P, alpha, epilogue scratch) is free
     first = false;
     run_segment(bc.nfull + cr - plan_div(qt * span, C));
@@ -1809,14 +1613,6 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   if ((int)blockIdx.x < nchunks) {
     compute();
   }
-#if BK_CLK
-  int clk_tickets = 0;
-  if (tid == 0) {   // experiments: shader cycles vs constant-rate (100 MHz) clock of this workgroup's compute part
-    long long* cb = reinterpret_cast<long long*>(a.ws_plan + (size_t)(a.obj0 + a.nobj) * kPlanInts + 16) + 8 * blockIdx.x;
-    cb[0] = (long long)__builtin_readcyclecounter() - t_entry;
-    cb[1] = (long long)__builtin_amdgcn_s_memrealtime() - t_real;
-  }
-#endif
 
   // =========================================== static part: drain the queue ===========================================
   // A workgroup pulls tickets of 12 x kStaticRowsPerTicket (object, channel) rows (one atomic per ticket: with a
@@ -1829,7 +1625,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   // not store: STRAIGHT-LINE code.  (With branches around the stores hipcc could not count the loads in flight and put
   // s_waitcnt vmcnt(0) in front of every unit, i.e. every unit waited for the previous unit's stores to land: 12-14 us
   // per ticket whatever else was tried.)
-  if (!(BK_ABLATE & 256)) {
+  {
     const bool vec4 = (hw & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.qv) | reinterpret_cast<uintptr_t>(a.out)) & 15) == 0;
     constexpr int kMaskUnits = 4096;                   // units of a wave's mask patch (longer rows are walked in pieces)
     constexpr int kUI = 7;                             // units per lane and step (7 x 64 = 448 >= the 405 units of a 480p row)
@@ -1946,17 +1742,13 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
               for (int e = 0; e < nvec; ++e) y[e] *= keep[e];              // x * 1 = x, x * 0 = +-0 / NaN: the reference's q_val * box (:358)
               const int qoff = ul < pn ? off : kOOB;
               const int moff = (ul < pn && (m >> 4) == (V4 ? 15u : 1u)) ? off : kOOB;   // (mixed units: the list pass)
-#if !(BK_STATIC_ABL & 1)
               if (V4) {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rs_q, qoff, 0, BK_OUT_AUX);
-                __builtin_amdgcn_raw_buffer_store_b128(mu4, rs_m, moff, 0, BK_OUT_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rs_q, qoff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(mu4, rs_m, moff, 0, 0);
               } else {
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[0]), rs_q, qoff, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mu), rs_m, moff, 0, 0);
               }
-#else
-              asm volatile("" :: "v"(y), "v"(qoff), "v"(moff));
-#endif
             }
           }
           // ---- the few units with cells on both sides of the box edge: one lane per unit, per-cell stores
@@ -2000,9 +1792,6 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     }
     __syncthreads();
     int ticket = sld(sflag);
-#if BK_CLK
-    int clk_tickets_ = 0;
-#endif
     while (ticket < ntickets) {
       lds_barrier();                                   // (everybody has read sflag)
       int t_next = 0;                                  // the next ticket flies while this one is worked on
@@ -2012,21 +1801,8 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
       if (tid == 0) sflag = t_next;
       lds_barrier();
       ticket = sld(sflag);
-#if BK_CLK
-      ++clk_tickets_;
-#endif
     }
-#if BK_CLK
-    clk_tickets = clk_tickets_;
-#endif
   }
-#if BK_CLK
-  if (tid == 0) {   // experiments: static tickets this workgroup served, and when it left (100 MHz ticks since entry)
-    long long* cb = reinterpret_cast<long long*>(a.ws_plan + (size_t)(a.obj0 + a.nobj) * kPlanInts + 16) + 8 * blockIdx.x;
-    cb[2] = clk_tickets;
-    cb[3] = (long long)__builtin_amdgcn_s_memrealtime() - t_real;
-  }
-#endif
   // (the queue word is NOT reset here: the launcher clears the control block before every launch -- a last-one-out counter
   //  was another 256 same-word atomics at the very end of the kernel)
 }
@@ -2147,7 +1923,6 @@ int launch_bank_main(const BankReadArgs& m, hipStream_t st) {
   a.T = m.T;
   a.T_dev = m.T_dev;
   a.gate = m.gate;
-  a.trace_slot = m.slots - 1;
   a.qscale = 1.44269504088896341f / sqrtf((float)kDe) * kBankScale;   // (the un-scaling is kSraw in the soft-max)
   // Objects are planned together in groups of <= kMaxObj; a group's partial slots start at
   // bank_group_slot0() and hold at most target + nobj * (query tiles) segments.

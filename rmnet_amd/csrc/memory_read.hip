@@ -882,11 +882,7 @@ int launch_memory_read(const MemReadArgs& m, hipStream_t st) {
 
 size_t bank_read_ws_bytes(int no, int h, int w) {
   const size_t slots = bank_total_slots(no, h * w);
-  return align256(slots * kDo * kQT * 4) + align256(slots * 2 * kQT * 4) + align256((size_t)no * kPlanInts * 4)
-#ifdef BK_CLK
-         + 16384
-#endif
-      ;
+  return align256(slots * kDo * kQT * 4) + align256(slots * 2 * kQT * 4) + align256((size_t)no * kPlanInts * 4);
 }
 
 size_t bank_read_ws_bytes_T(int no, int h, int w, int T) {

@@ -47,8 +47,8 @@ def main():
         import bench
         H, W, K, T = bench.H, bench.W, bench.K_CH, bench.T_MEM
         abytes = bench.algorithmic_bytes(8 * (K - 1), T, 30, 54)
-        prec = 'f16' if sys.argv[-1] == 'f16' else 'split'
-        prof = {'kernel': 'bk_main<%d>' % (1 if prec == 'f16' else 3), 'read_precision': prec, 'source_hash': bench.source_hash(),
+        prec = sys.argv[-1] if sys.argv[-1] in ('f16', 'qx') else 'split'
+        prof = {'kernel': 'bk_main<%d>' % {'f16': 1, 'qx': 2, 'split': 3}[prec], 'read_precision': prec, 'source_hash': bench.source_hash(),
                 'command': 'tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE (then WRITE_SIZE, separate pass) --kernel-trace -- '
                            'python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extras --read-precision %s (8 object-frames per launch)' % prec,
                 'fetch_size_kb_per_launch': round(fetch['bk_main'][0], 1), 'write_size_kb_per_launch': round(write['bk_main'][0], 1),
@@ -59,7 +59,7 @@ def main():
                 'other_kernels_same_run': {k: {'fetch_size_kb_per_launch': round(fetch.get(k, (0, 0))[0], 1),
                                                'write_size_kb_per_launch': round(write.get(k, (0, 0))[0], 1)}
                                            for k in sorted(set(fetch) | set(write)) if k != 'bk_main'}}
-        fname = 'bk_main_f16_hbm_traffic.json' if prec == 'f16' else 'bk_main_hbm_traffic.json'
+        fname = {'f16': 'bk_main_f16_hbm_traffic.json', 'qx': 'bk_main_qx_hbm_traffic.json', 'split': 'bk_main_hbm_traffic.json'}[prec]
         json.dump(prof, open(os.path.join(ROOT, 'profiles', fname), 'w'), indent=1)
         print('wrote profiles/' + fname)
 

@@ -9,7 +9,7 @@ ROOT=$PWD
 export TMPDIR=/tmp
 # PRECISION=f16 bash tools/pmc_traffic.sh does the same for the fp16-operand mode -> gpurun_out/pmc_f16/, profiles/bk_main_f16_hbm_traffic.json
 PREC=${PRECISION:-split}
-out=gpurun_out/pmc; [ "$PREC" = f16 ] && out=gpurun_out/pmc_f16
+out=gpurun_out/pmc; [ "$PREC" != split ] && out=gpurun_out/pmc_$PREC
 mkdir -p $out
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -19,5 +19,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   grep -E "bk_main|mr_combine|bk_append|region_reduce|region_fill|flow_affine|soft_aggregate" "$f" > $ROOT/$out/$c.csv || true
   tail -1 /tmp/pmc_$c.log | cut -c1-300
 done
-name=bk_main_hbm_traffic.json; [ "$PREC" = f16 ] && name=bk_main_f16_hbm_traffic.json
+name=bk_main_hbm_traffic.json; [ "$PREC" != split ] && name=bk_main_${PREC}_hbm_traffic.json
 python $ROOT/tools/pmc_traffic.py $ROOT/$out --write-profile $PREC && cp $ROOT/profiles/$name $ROOT/$out/

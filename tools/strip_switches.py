@@ -101,6 +101,12 @@ subs = [
 ]
 for a, b in subs:
     text = re.sub(a, b, text)
+# the trace plumbing (BK_TRACE builds only)
+text = re.sub(r', long long t_entry,', ',', text)
+text = re.sub(r', t_entry, ', ', ', text)
+text = re.sub(r'\n  const long long t_entry = [^\n]*', '', text)
+text = re.sub(r'\n  int trace_slot;[^\n]*', '', text)
+text = re.sub(r'\n  a\.trace_slot = [^\n]*', '', text)
 for k, (name, _) in KEEP_AS_CONSTANT.items():
     text = re.sub(r'\b%s\b' % k, name, text)
 for k, v in LITERALS.items():
