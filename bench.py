@@ -8,9 +8,9 @@ process per GPU, RCCL over xGMI, rendezvous on 127.0.0.1 at a free port) and ran
 torch.distributed.run (the driver's form) it is one of those ranks.
 
 Workload (BASELINE.json configs[1], synthetic): 480x854 clips, 1 object each (K = 2 mask channels), memory pinned at T = 5
-frames (4 committed + the tentative previous frame); ``--clips-per-gpu`` (default 8) independent clips are batched on every
-GPU -- videos share nothing, and a single 480p stream cannot fill 256 CUs (measured on MI355X: 164 / 194 / 227 / 248 frames/s
-at 1 / 2 / 4 / 8 clips).  One "step" = one frame of the reference's loop (models/rmnet.py:410-450, utils/helpers.py:55):
+frames (4 committed + the tentative previous frame); ``--clips-per-gpu`` (default 16; 8 until round 4) independent clips are batched on
+every GPU -- videos share nothing, and a single 480p stream cannot fill 256 CUs (measured on MI355X: 164 / 227 / 254 / 261 / 261 / 267
+frames/s at 1 / 4 / 8 / 12 / 16 / 32 clips; at 16 the read's launch is 208 workgroups of one (object, query tile) pair each: no merge).  One "step" = one frame of the reference's loop (models/rmnet.py:410-450, utils/helpers.py:55):
 TinyFlowNet on the frame pair, memorise frame t-1 (ResNet-50 memory encoder + KV head + region boxes + bank write), regional
 query boxes from the flow-warped previous mask, query encoder + KV head, fused regional memory read, decoder, soft
 aggregation, soft-max.  Convolutions fp32 (the reference's dtype); the arithmetic of the memory read is ``--read-precision``
@@ -52,6 +52,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 H, W, K_CH, T_MEM = 480, 854, 2, 5
+DEFAULT_CLIPS = 16            # clips batched per GPU in the default run (--clips-per-gpu)
 DE, DO = 128, 512
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -385,9 +386,11 @@ def main():
     ap.add_argument('--fold-bn', action='store_true',
                     help='fold eval-mode BatchNorm into the trunk convolutions (measured: no gain at 4 clips/GPU)')
     ap.add_argument('--channels-last', action='store_true', help='conv stacks in NHWC memory format (experiment)')
-    ap.add_argument('--clips-per-gpu', type=int, default=8,
-                    help='independent clips batched on every GPU (one 480p clip cannot fill 256 CUs; measured '
-                         'on MI355X: 164 / 194 / 227 / 248 / 247 frames/s at 1 / 2 / 4 / 8 / 10 clips)')
+    ap.add_argument('--clips-per-gpu', type=int, default=DEFAULT_CLIPS,
+                    help='independent clips batched on every GPU (one 480p clip cannot fill 256 CUs; measured on MI355X in round 5, '
+                         'profiles/r05_c_plan_and_tail_experiments.md: 164 / 227 / 253.7 / 261.2 / 260.6 / 267.4 frames/s at 1 / 4 / 8 / 12 / 16 / 32 clips). '
+                         '16 (default since round 5; 8 before) = 16 x 13 (object, query tile) pairs = 208 workgroups of the read, each walking its '
+                         'pair\'s whole memory: no split, no partial results, no merge')
     ap.add_argument('--graph', action='store_true', help='replay the frame step as one captured HIP graph')
     ap.add_argument('--read-precision', choices=('auto', 'split', 'qx', 'f16'), default='auto',
                     help="arithmetic of the bank read in the timed region: 'auto' (default, = RMNet's default) picks 'f16' for clips with one "
@@ -562,6 +565,27 @@ def main():
             net._profile_events = None
             other_ms[om] = [events.elapsed_ms(events.ev[3 * i], events.ev[3 * i + 2]) - 2e-3 * ev_floor_us for i in range(args.steps)]
         bank.precision = args.read_precision
+        # ... and the timed arithmetic at the launch size of rounds 1-4 (8 object-frames per launch: every pair is cut in two, the
+        # partial results are merged by the last arriver), inside the same loop on the first 8 clips (MIOpen immediate mode for these
+        # extra shapes: the read does not depend on the convolutions' algorithms, only on what they leave in the caches)
+        small_ms = None
+        if B > 8:
+            find = torch.backends.cudnn.benchmark
+            torch.backends.cudnn.benchmark = False
+            ctx8 = net._ClipContext(net, 8, K_CH, H, W, [K_CH - 1] * 8, dev)
+            bank8 = net.new_bank(ctx8, T_MEM)
+            f8, m8 = frames[:8], masks[:8]
+            for t in range(1, T_MEM):
+                net.frame_step(ctx8, bank8, f8[:, t - 1], m8[:, t - 1], f8[:, t], tfn._forward(f8[:, t], f8[:, t - 1]), commit=True)
+            for i in range(3 + args.steps):
+                t = T_MEM + (i % (n_clip - T_MEM))
+                net._profile_events = tuple(events.ev[3 * (i - 3):3 * (i - 3) + 3]) if i >= 3 else None
+                net.frame_step(ctx8, bank8, f8[:, t - 1], m8[:, t - 1], f8[:, t], tfn._forward(f8[:, t], f8[:, t - 1]), commit=False)
+            torch.cuda.synchronize()
+            net._profile_events = None
+            small_ms = [events.elapsed_ms(events.ev[3 * i], events.ev[3 * i + 2]) - 2e-3 * ev_floor_us for i in range(args.steps)]
+            torch.backends.cudnn.benchmark = find
+            del bank8, ctx8
     main_raw = sum(main_ms) / len(main_ms)
     main_avg = max(main_raw - ev_floor_us * 1e-3, 1e-6)     # kernel time = bracket - empty-bracket floor
     abytes = algorithmic_bytes(B * (K_CH - 1), T_MEM, ctx.h, ctx.w)
@@ -654,8 +678,8 @@ def main():
                     'hand_written_rmnet_kernels': round(own / tot, 4), 'convolution_gemm_kernels': round(conv / tot, 4),
                     'other_torch_kernels': round((other - conv) / tot, 4), 'gpu_busy_ms_per_step': round(tot / 3e3, 3),
                     'largest_kernels': [{'name': k[:80], 'share': round(v / tot, 4)} for k, v in big],
-                    'note': 'torch.profiler device records of 3 steps (8 clips per GPU); box-to-box variance of the headline value '
-                            'follows the convolution share (MIOpen solver choice), not the hand-written kernels'}
+                    'note': 'torch.profiler device records of 3 steps (%d clips per GPU); box-to-box variance of the headline value '
+                            'follows the convolution share (MIOpen solver choice), not the hand-written kernels' % B}
         except Exception as exc:                          # (profiler support depends on the torch / ROCm build)
             extras['timed_region_gpu_time_share'] = {'error': repr(exc)[:200]}
         _phase('extras: single stream')
@@ -845,6 +869,16 @@ def main():
                              "one object, live mask boundaries: f16 0.99993-0.99997, qx / split / exact fp32 0.99999-1.00000; 3 / 5 objects: exact fp32 "
                              ">= 0.9997, qx >= 0.9993, f16 0.9986-0.9995" % args.read_precision)
             line['roofline']['modes'] = modes
+            if small_ms is not None:
+                s_us = 1e3 * sum(small_ms) / len(small_ms)
+                ab8 = algorithmic_bytes(8 * (K_CH - 1), T_MEM, ctx.h, ctx.w)
+                line['roofline']['launch_sizes'] = {
+                    str(B): {'object_frames': B, 'avg_us': round((main_avg + comb_avg) * 1e3, 2), 'frac': round(op_achieved / HBM_PEAK_GBS, 4)},
+                    '8': {'object_frames': 8, 'avg_us': round(s_us, 2), 'GBps': round(ab8 / s_us / 1e3, 1), 'frac': round(ab8 / s_us / 1e3 / HBM_PEAK_GBS, 4)},
+                    'note': 'the timed arithmetic at this run\'s launch size and at 8 object-frames per launch (the default of rounds 1-4), the '
+                            'latter inside the same frame loop on the first 8 clips.  At 16 every (object, query tile) pair is ONE workgroup that walks '
+                            'the pair\'s whole memory (208 workgroups, no partial results, no merge); at 8 every pair is cut in two and merged by its '
+                            'last arriver (DESIGN.md section 4 [r5])'}
         if extras is not None and extras.get('single_stream_fps'):
             line['config']['workload'] += ' -- value = %d clips batched per GPU; ONE 480p stream alone: %.1f frames/s' % (B, extras['single_stream_fps'])
         else:

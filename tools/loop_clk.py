@@ -16,7 +16,7 @@ dev = torch.device('cuda', 0)
 torch.set_grad_enabled(False)
 torch.backends.cudnn.benchmark = os.environ.get('FIND', '0') == '1'
 H, W, K, T = bench.H, bench.W, bench.K_CH, bench.T_MEM
-B = 8
+B = int(os.environ.get('CLIPS', bench.DEFAULT_CLIPS))   # clips per GPU (CLIPS=8: the launch of rounds 1-4)
 net = networks.procedural_init_(RMNet(None, read_precision=prec)).to(dev).eval()
 tfn = networks.procedural_init_(TinyFlowNet(None)).to(dev).eval()
 net.fuse_epilogues(); tfn.fuse_epilogues()

@@ -46,11 +46,11 @@ def main():
     if '--write-profile' in sys.argv and 'bk_main' in fetch and 'bk_main' in write:
         import bench
         H, W, K, T = bench.H, bench.W, bench.K_CH, bench.T_MEM
-        abytes = bench.algorithmic_bytes(8 * (K - 1), T, 30, 54)
+        abytes = bench.algorithmic_bytes(bench.DEFAULT_CLIPS * (K - 1), T, 30, 54)
         prec = sys.argv[-1] if sys.argv[-1] in ('f16', 'qx') else 'split'
         prof = {'kernel': 'bk_main<%d>' % {'f16': 1, 'qx': 2, 'split': 3}[prec], 'read_precision': prec, 'source_hash': bench.source_hash(),
                 'command': 'tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE (then WRITE_SIZE, separate pass) --kernel-trace -- '
-                           'python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extras --read-precision %s (8 object-frames per launch)' % prec,
+                           'python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extras --read-precision %s (%d object-frames per launch)' % (prec, bench.DEFAULT_CLIPS),
                 'fetch_size_kb_per_launch': round(fetch['bk_main'][0], 1), 'write_size_kb_per_launch': round(write['bk_main'][0], 1),
                 'hbm_bytes_per_launch': int(1024 * (FETCH_FACTOR * fetch['bk_main'][0] + WRITE_FACTOR * write['bk_main'][0])),
                 'fetch_factor': FETCH_FACTOR, 'write_factor': WRITE_FACTOR,
