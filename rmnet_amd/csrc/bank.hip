@@ -406,7 +406,7 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
   const int o = wk.o;
   const int l15 = lane & 15, g = lane >> 4;
   const int jt0 = wk.jt0, ntl = wk.ntl;
-    // query fragments (B operand of S): lane (query l15, group g) holds channels 32ks + 8g + e
+  // query fragments (B operand of S): lane (query l15, group g) holds channels 32ks + 8g + e
   half8 qh[4], ql[4];
   {
     const int qn = wk.qt * kQT + wave * 16 + l15;
@@ -585,17 +585,17 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
     k_frags(f, 2);                                   // for the MFMAs of iteration 0
   }
   __syncthreads();                                   // B: P(0) visible
-    int kslot = 3;                                     // ring slot of tile n+3
+  int kslot = 3;                                     // ring slot of tile n+3
   for (int n = 0; n < ntl; ++n) {
-        {
+    {
       const int l1 = cs.seek(jt0 + n + 1);
       const int nvalid = n + 1 < ntl ? tarea[cs.tt] - l1 * kJT : 0;
       f32x4 s0, s1;
       s_mfma(f, s0, s1);                             // tile n+2 (fragments read before the barrier)
       __builtin_amdgcn_sched_barrier(0);             // MFMAs first (the pipe is idle right after a barrier)
-      
+
       soft_max(sp0, sp1, nvalid, (n + 1) & 1);       // tile n+1
-            sp0 = s0; sp1 = s1;
+      sp0 = s0; sp1 = s1;
       k_frags(f, kslot);                             // tile n+3: its LDS latency hides under the barrier
       {
         // K ring: tile n+4 (requested one iteration ago) -> slot n%4, whose last reader (tile n) passed
@@ -606,12 +606,12 @@ __device__ inline void producer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
       }
     }
     kslot = (kslot + 1) & 3;
-        __syncthreads();
-      }
+    __syncthreads();
+  }
   m_out = mref * kSraw;                                // log2 domain; the segment's epilogue takes it from here
   l_out = lsum;
   query_range_check(b, qh, wk.qt * kQT + wave * 16 + l15 < wk.Mq);
-  }
+}
 
 // ---------------------------------------------------------------- consumers: O += V P, K ring
 __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
@@ -623,7 +623,7 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
   const int jt0 = wk.jt0, ntl = wk.ntl;
   const size_t so0 = (size_t)o * b.Tcap;
   const size_t tiles_per_slot = (size_t)(b.hwp / kJT);
-    // V: fragment-ordered planes; this wave's first d-tile and its lane inside a tile's 32 KB plane
+  // V: fragment-ordered planes; this wave's first d-tile and its lane inside a tile's 32 KB plane
   const int dt0 = kCDT * (wave - kProducers);
   const size_t vlane = (size_t)(dt0 * 64 + lane) * 16;
   auto v_tile = [&](int tt, int ll) { return ((so0 + tt) * tiles_per_slot + ll) * (size_t)(kDo * kJT * 2) + vlane; };
@@ -650,10 +650,10 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
     for (int it = 0; it < 4; ++it) acc[dt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();                                   // A: K tiles 0..3 visible
   __syncthreads();                                   // B: P(0) visible
-  
+
   for (int n = 0; n < ntl; ++n) {
     const int buf = n & 1;
-        const char* pfr = Pl_ + buf * kPbuf;
+    const char* pfr = Pl_ + buf * kPbuf;
     const f32x4 al = *reinterpret_cast<const f32x4*>(Al + buf * kQT + l15 * 4);
     half8 bh[4], bl[4];                              // all P fragments of this tile
 #pragma unroll
@@ -690,9 +690,9 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE (the scheduler sinks them to the end)
     }
-        __syncthreads();   // the one barrier per tile
-      }
-  
+    __syncthreads();   // the one barrier per tile
+  }
+
 }
 
 // ---- L2 prefetch of the fp16-operand walk.  Inside the frame loop nothing of the bank is in a cache when the read starts (the
@@ -780,7 +780,7 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
   const int l15 = lane & 15, g = lane >> 4;
   const int jt0 = wk.jt0, ntl = wk.ntl;
   const int nst = (ntl + 1) >> 1;                    // steps of two tiles (the last one may be half empty)
-    half8 qh[4], ql[kQx ? 4 : 1];
+  half8 qh[4], ql[kQx ? 4 : 1];
   {
     const int qn = wk.qt * kQT + wave * 16 + l15;
     const bool qvalid = qn < wk.Mq;
@@ -926,11 +926,11 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
   }
   __syncthreads();                                   // B: P(0), P(1) visible; ring slot 0 free
   __syncthreads();                                   // C: K step 4 in slot 0
-    int pbuf = 2;                                      // (n + 2) % 3
+  int pbuf = 2;                                      // (n + 2) % 3
   for (int n = 0; n < nst; ++n) {
-        mask_ragged(sp, nva, nvb);
+    mask_ragged(sp, nva, nvb);
     __builtin_amdgcn_sched_barrier(0);
-        S4 s0;
+    S4 s0;
     s_mfma(f, s0);                                   // step n+3
     soft_max(sp, pbuf);                              // step n+2
     // one S MFMA, then a few soft-max VALU instructions, and so on: issued back to back the 16 MFMAs of this wave wait
@@ -941,18 +941,18 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
       __builtin_amdgcn_sched_group_barrier(0x002, kQx ? (kSoftmaxInterleave + 1) / 2 : kSoftmaxInterleave, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-        sp = s0;
+    sp = s0;
     k_frags(f, n & 3);                               // step n+4
     step_valid(n + 3, nva, nvb);                     // (LDS round trips: they end under the barrier)
     pbuf = pbuf == 2 ? 0 : pbuf + 1;
     pf.touch(n + kPfSteps, wave, kProducers, lane);
-        __syncthreads();
-      }
+    __syncthreads();
+  }
   m_out = mref * kSraw;
   l_out = lsum;
   query_range_check(b, qh, wk.qt * kQT + wave * 16 + l15 < wk.Mq);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the patch is free again; the youngest touch is kPfSteps steps old)
-  }
+}
 
 __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
                                          const int* tpre, int wave, int lane,
@@ -962,7 +962,7 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
   const int l15 = lane & 15;
   const int jt0 = wk.jt0, ntl = wk.ntl;
   const int nst = (ntl + 1) >> 1;
-    const size_t so0 = (size_t)o * b.Tcap;
+  const size_t so0 = (size_t)o * b.Tcap;
   const size_t tiles_per_slot = (size_t)(b.hwp / kJT);
   const int dt0 = kCDT * (wave - kProducers);
   const size_t vlane = (size_t)(dt0 * 64 + lane) * 16;
@@ -1040,7 +1040,7 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
   k_load(kr, 5);
   p_frags(0);
   __syncthreads();                                   // C
-    int pnext = 1;                                     // (n + 1) % 3
+  int pnext = 1;                                     // (n + 1) % 3
   // addresses of the NEXT step's V tiles: found before the barrier, so that an iteration starts with MFMAs
   const char *nva, *nvb;
   auto v_next = [&](int step) {
@@ -1051,7 +1051,7 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
   };
   v_next(1);
   for (int n = 0; n < nst; ++n) {
-        k_store(kr, (n + 1) & 3);                        // step n+5 (its slot was last read in iteration n-3)
+    k_store(kr, (n + 1) & 3);                        // step n+5 (its slot was last read in iteration n-3)
     k_load(kr, n + 6);
     if (__any(al[0] != 1.0f || al[1] != 1.0f || al[2] != 1.0f || al[3] != 1.0f)) {
 #pragma unroll
@@ -1074,9 +1074,9 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
     p_frags(pnext);                                  // step n+1: published an iteration ago; lands under the barrier
     pnext = pnext == 2 ? 0 : pnext + 1;
     v_next(n + 2);
-        __syncthreads();
-      }
+    __syncthreads();
   }
+}
 
 constexpr int kMaxObj = kBankMaxObj;    // objects planned together in one launch (the launcher groups more)
 

@@ -87,8 +87,7 @@ src = open(sys.argv[1]).read().split('\n')
 text = '\n'.join(strip(src))
 # in-code uses of the switches at their default values
 subs = [
-    (r'BK_STAMP\(\);[^\n]*\n', ''),                                           # trace stamps (whole statement lines)
-    (r'\n\s*BK_STAMP\(\);', ''),
+    (r'\n[ \t]*BK_STAMP\(\);[^\n]*', ''),                                   # trace stamps (whole statement lines)
     (r' && !\(\(BK_ABLATE & 2048\) && \(n & 1\)\)', ''),
     (r'\n *if \(BK_ABLATE & 4096\) \{[^\n]*\}[^\n]*', ''),
     (r'\n *if \(BK_ABLATE & 1024\) return;', ''),
