@@ -32,7 +32,9 @@ f16 = os.environ.get('RMNET_BANK_PRECISION') == 'f16'
 plabels = (['top->head (mask)', 'S MFMAs + soft-max', 'K frags', 'barrier', '->next top'] if f16 else
            ['top->MFMAs issued', 'soft-max', 'K frags', 'barrier', '->next top'])
 for name, a, labels in (('producer wave0', tr[:1024], plabels),
-                        ('consumer wave4', tr[1024:2048], ['top->PV done', 'barrier', '->next top'])):
+                        ('consumer wave (BK_TRACE_WAVE)', tr[1024:2048],
+                         ['top->K ring fed', '->dt0 done', 'dt1', 'dt2', 'dt3', 'P frags + V addresses', 'barrier', '->next top']
+                         if os.environ.get('TRACE2') else ['top->PV done', 'barrier', '->next top'])):
     a = a[a != 0]
     d = np.diff(a)
     print(name, 'n stamps', len(a), 'total', a[-1] - a[0])
