@@ -34,7 +34,7 @@ plabels = (['top->head (mask)', 'S MFMAs + soft-max', 'K frags', 'barrier', '->n
 for name, a, labels in (('producer wave0', tr[:1024], plabels),
                         ('consumer wave (BK_TRACE_WAVE)', tr[1024:2048],
                          ['top->K ring fed', '->dt0 done', 'dt1', 'dt2', 'dt3', 'P frags + V addresses', 'barrier', '->next top']
-                         if os.environ.get('TRACE2') else ['top->PV done', 'barrier', '->next top'])):
+                         if os.environ.get('TRACE2') == '1' else ['top->K data there', 'K stored', 'K requested', '->dt0 done', 'dt1', 'dt2', 'dt3', 'P frags + V addresses', 'barrier', '->next top'] if os.environ.get('TRACE2') == '2' else ['top->PV done', 'barrier', '->next top'])):
     a = a[a != 0]
     d = np.diff(a)
     print(name, 'n stamps', len(a), 'total', a[-1] - a[0])
