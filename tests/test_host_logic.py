@@ -359,3 +359,30 @@ def test_launch_plan_invariants_on_the_host(tmp_path):
     assert cc.returncode == 0, cc.stderr[-2000:]
     run = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0 and 'plan_check ok' in run.stdout, run.stdout[-3000:]
+
+
+def test_bench_becomes_its_own_launcher_for_several_gpus(monkeypatch):
+    """`python bench.py --gpus N` from a plain shell (WORLD_SIZE unset): bench.py re-executes its own command line as N ranks under
+    torch.distributed.run on 127.0.0.1 at a free port, with dmabuf IPC for RCCL, and hands the exit code back.  (The GPU suite runs
+    the real thing with two gloo ranks on one GPU: test_bench_launches_its_own_ranks.)"""
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, 'call', fake_call)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '3', '--warmup', '1'])
+    monkeypatch.delenv('HSA_ENABLE_IPC_MODE_LEGACY', raising=False)
+    assert bench._self_launch(4) == 7
+    cmd = seen['cmd']
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run']
+    assert '--nnodes=1' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '4' and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert 1024 <= int(cmd[cmd.index('--master-port') + 1]) <= 65535
+    i = cmd.index(os.path.join(ROOT, 'bench.py'))
+    assert cmd[i + 1:] == ['--gpus', '4', '--steps', '3', '--warmup', '1']
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    assert bench.DEFAULT_CLIPS == 16
