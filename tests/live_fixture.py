@@ -91,7 +91,8 @@ def _r16(x):
 
 def rounded_reader(mode, mutate=None):
     """MemoryReader.forward with the roundings of a bank arithmetic, as a drop-in for ``oracle.torch_memory_read``.
-    ``mode``: 'exact' | 'f16' (K, q, P, V rounded) | 'mixed' (P, V rounded; logits exact) | 'qx' (f16 with an exact query)
+    ``mode``: 'exact' | 'f16' (K, q, P, V rounded) | 'qx' (f16 with an exact query) | 'mixed' (P, V rounded, logits exact: an
+    arithmetic that was built, measured and dropped in round 5 -- kept here as a pricing point)
     or any '+'-joined subset of {'K','q','P','V'}.  ``mutate``: None | 'zero' (memory half of the read-out zeroed) |
     ('noise', fraction) (Gaussian noise of that fraction of the read-out's standard deviation)."""
     sets = {'exact': '', 'f16': 'K+q+P+V', 'mixed': 'P+V', 'qx': 'K+P+V'}

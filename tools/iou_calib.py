@@ -1,7 +1,7 @@
 # -*- coding: utf-8 -*-
 """Calibration of the north star's IoU bar ("mask IoU within 1e-3 of the reference CPU path"): the CPU path
 (oracle.OracleRMNet, plain torch + C ops) against the GPU frame loop with the bank read in its arithmetics -- exact fp32
-(TensorBank + mr_main), split fp16 (3 MFMA terms), mixed (logits in 3 terms, O = V P in 1) and fp16 operands (1 term).
+(TensorBank + mr_main), split fp16 (3 MFMA terms), qx (fp16 operands with an exact query) and fp16 operands (1 term).
 One row per (clip, arithmetic): per-object label IoU vs the CPU path over the whole clip, the worst single-frame IoU, the largest
 probability difference and -- one-object clips -- the largest difference of the live foreground logits; then the same rows against
 the exact-fp32 GPU run (what the arithmetic alone does).
@@ -25,7 +25,7 @@ want = sys.argv[3].split(',') if len(sys.argv) > 3 else ['3o480', '5o480', '3o72
 size = float(sys.argv[4]) if len(sys.argv) > 4 else 1.1          # blob radius scale of rmnet_amd.synthetic.synthetic_clip
 every_override = int(os.environ.get('EVERY', '0'))
 CASES = {'1o480': (1, 480, 854, 5, 1), '3o480': (3, 480, 854, 5, 3), '5o480': (5, 480, 854, 2, 4), '3o720': (3, 720, 1280, 3, 5)}
-MODES = os.environ.get('MODES', 'exact,split,mixed,f16').split(',')
+MODES = os.environ.get('MODES', 'exact,split,qx,f16').split(',')
 torch.set_grad_enabled(False)
 torch.set_num_threads(nt)
 oracle.set_num_threads(nt)
