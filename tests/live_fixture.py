@@ -32,6 +32,8 @@ LIVE_CLIPS = {
     'live480-a': dict(seed=11, H=480, W=854, N=7, every=1, size=2.1, delta=-5.5),
     'live480-b': dict(seed=1, H=480, W=854, N=7, every=1, size=2.1, delta=-5.0),      # softer boundary: the cover grows 0.22 -> 0.36
     'live480-c': dict(seed=2, H=480, W=854, N=7, every=2, size=2.1, delta=-5.25),     # every second frame memorised
+    # 720x1280 (the resolution of BASELINE configs[3] / [4]), memory growing to T = 4
+    'live720': dict(seed=5, H=720, W=1280, N=5, every=1, size=2.1, delta=-5.0),
     # small version for the CPU-only suite
     'live240': dict(seed=11, H=240, W=432, N=5, every=1, size=2.1, delta=-5.23),
 }

@@ -1881,10 +1881,10 @@ def _table(line):
 LIVE_LOGIT_BAR = 2e-2
 
 
-@pytest.mark.parametrize('mode', ['auto', 'exact', 'split', 'qx', 'f16'])
-@pytest.mark.parametrize('name', ['live480-a', 'live480-b', 'live480-c'])
+@pytest.mark.parametrize('name,mode', [(n, m) for n in ('live480-a', 'live480-b', 'live480-c') for m in ('auto', 'exact', 'split', 'qx', 'f16')] +
+                         [('live720', 'auto'), ('live720', 'exact'), ('live720', 'qx')])      # (720x1280: the resolution of configs[3] / [4])
 def test_live_boundary_clips_meet_the_bar_in_every_arithmetic(name, mode, oracle_mod):
-    """The north star's bar -- mask IoU within 1e-3 of the CPU path -- on one-object 480x854 clips whose masks HAVE a boundary
+    """The north star's bar -- mask IoU within 1e-3 of the CPU path -- on one-object 480x854 (and 720x1280) clips whose masks HAVE a boundary
     (cover 10-60 %, >= 1 % of the pixels within 0.1 of the threshold on every frame: asserted), for the GPU loop with the
     exact-fp32 read, the three bank arithmetics and the default.  Also compared: the logits (LIVE_LOGIT_BAR) and the
     probabilities.  That this comparison CAN fail is test_mutated_memory_read_fails_the_parity_metric."""
