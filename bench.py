@@ -413,7 +413,11 @@ def main():
         # started from a plain shell (`python bench.py --gpus N`): become the launcher of N ranks of this same command line
         # (one process per GPU, RCCL over xGMI) and relay rank 0's JSON line
         sys.exit(_self_launch(args.gpus))
-    rank, world, local = rd.init_from_env(args.dist_backend)
+    # (an explicit --dist-backend with --gpus 1 creates a ONE-rank process group: the collectives of the N > 1 path then run through
+    #  that backend -- RCCL for 'nccl' -- on the one GPU a test box has)
+    rank, world, local = rd.init_from_env(args.dist_backend, force_group=args.dist_backend is not None)
+    import torch.distributed as tdist
+    grouped = tdist.is_initialized()
     if args.dist_backend == 'gloo':
         local = local % max(torch.cuda.device_count(), 1)
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
@@ -511,11 +515,10 @@ def main():
     assert bool(torch.isfinite(out).all())
     _phase('timed region done')
     multi = None
-    if world > 1:
+    if grouped:
         # Outside the timed region: every rank's own rate, and the path's ONE collective step -- the gather of the per-clip
         # label maps to rank 0 (rmnet_amd.dist.gather_label_maps: header all_gather + one padded gather) -- timed
         # on the last frame's label maps (uint8 [1, H, W] per clip), payloads resident on the GPU.
-        import torch.distributed as tdist
         cdev = dev if tdist.get_backend() == 'nccl' else torch.device('cpu')
         mine_t = torch.tensor([float(elapsed_local)], dtype=torch.float64, device=cdev)
         all_t = [torch.zeros_like(mine_t) for _ in range(world)]
@@ -893,8 +896,7 @@ def main():
             line['cpu_baseline'] = cpu_baseline()
             _phase('cpu baseline done')
         print(json.dumps(line), flush=True)
-    if world > 1:
-        import torch.distributed as tdist
+    if grouped:
         tdist.destroy_process_group()
 
 

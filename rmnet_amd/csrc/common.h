@@ -231,12 +231,12 @@ __host__ __device__ inline int plan_div(int x, int c) {
   return x / c;
 #endif
 }
-struct BankChunks { int C, Cb, nfull, R, nrem, nch, sc, eq; };
+struct BankChunks { int C, Cb, nfull, R, nrem, nch, sc, eq, bq, br; };
 // `blocks` is a launch-wide decision of the plan (bank.hip):
 //   0  plain: nfull = njt / C aligned column blocks of C tiles + remainder chunks;
 //   1  "own blocks": as 0, but an object with no more tiles than a chunk is ONE column block of its own length (see below);
-//   2  EQUALISED: every object is cut into nfull = ceil(njt / C) column blocks of (almost) equal length <= C -- block b covers
-//      tiles [b njt / nfull, (b + 1) njt / nfull) -- and there are NO remainder chunks: every chunk is one segment, a pair has
+//   2  EQUALISED: every object is cut into nfull = ceil(njt / C) column blocks of (almost) equal length <= C -- the first
+//      njt mod nfull blocks have one tile more than the others -- and there are NO remainder chunks: every chunk is one segment, a pair has
 //      exactly nfull partials.  The plan takes it when it fits the workgroups at (nearly) the chunk length the plain plan found:
 //      the bench launch (objects of 119 tiles, C = 58) then walks 60 + 59 tiles with two partials per pair instead of
 //      58 + 58 + 3 with three, and the multi-segment remainder chunks (a segment's fixed cost is ~12 tiles of the fp16 walk) are gone.
@@ -245,11 +245,14 @@ __host__ __device__ inline BankChunks bank_chunks(int nqt, int njt, int C, int s
   k.C = C;
   k.sc = segcost;
   k.eq = 0;
+  k.bq = k.br = 0;
   k.Cb = C;                          // length of an aligned column block
   if (blocks == 2) {
     k.eq = 1;
     k.nfull = njt > 0 ? plan_div(njt + C - 1, C) : 0;
-    k.Cb = k.nfull > 0 ? plan_div(njt + k.nfull - 1, k.nfull) : 0;   // (the longest block; bank_block_range() has each block's own)
+    k.bq = k.nfull > 0 ? plan_div(njt, k.nfull) : 0;              // every block has bq tiles, the first br of them one more
+    k.br = njt - k.bq * k.nfull;                                  // (one division of small operands: plan_div's < 2^22 contract holds)
+    k.Cb = k.bq + (k.br > 0 ? 1 : 0);                             // (the longest block; bank_block_range() has each block's own)
     k.R = 0;
     k.nrem = 0;
     k.nch = nqt * k.nfull;
@@ -270,9 +273,10 @@ __host__ __device__ inline BankChunks bank_chunks(int nqt, int njt, int C, int s
 }
 // Tiles [j0, j0 + n) of aligned column block `blk` of an object with njt tiles.
 __host__ __device__ inline void bank_block_range(const BankChunks& k, int njt, int blk, int& j0, int& n) {
-  if (k.eq) {
-    j0 = plan_div(blk * njt, k.nfull);
-    n = plan_div((blk + 1) * njt, k.nfull) - j0;
+  if (k.eq) {   // (round-5 advisor: floor(blk njt / nfull) took plan_div's numerator to nfull x njt, beyond its documented 2^22 for long banks)
+    j0 = blk * k.bq + (blk < k.br ? blk : k.br);
+    n = k.bq + (blk < k.br ? 1 : 0);
+    (void)njt;
   } else {
     j0 = blk * k.Cb;
     n = k.Cb;

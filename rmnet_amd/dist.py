@@ -19,18 +19,27 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, force_group=False):
     """Initialise torch.distributed from torchrun's environment (RANK / WORLD_SIZE / LOCAL_RANK /
     MASTER_ADDR / MASTER_PORT).  Returns (rank, world_size, local_rank).  A single process without
-    those variables is rank 0 of 1 and no process group is created."""
+    those variables is rank 0 of 1 and no process group is created -- unless ``force_group`` asks for a
+    ONE-rank group (the collectives below then really go through the backend: how the RCCL branch is
+    executed on a box with one GPU)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_group) and not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29500')
+        if 'MASTER_PORT' not in os.environ:
+            if world > 1:
+                os.environ['MASTER_PORT'] = '29500'
+            else:                                       # a one-rank group: any free port will do
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(('127.0.0.1', 0))
+                    os.environ['MASTER_PORT'] = str(sk.getsockname()[1])
         if backend == 'nccl':
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world,

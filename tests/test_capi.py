@@ -99,5 +99,10 @@ def test_flag_constants_of_the_python_mirror_match_the_header():
     assert net.resolve_read_precision([1, 1, 1]) == 'f16' and net.resolve_read_precision([1, 3]) == 'qx'   # calibrated per-clip choice (profiles/r05_iou_calibration.md)
     assert RMNet(None, read_precision='f16').resolve_read_precision([5]) == 'f16'
     lib = _lib.load()
-    # the fp16 switch is the only flag rmnet_bank_read_f32_at knows: anything else is refused before any launch
-    assert lib.rmnet_bank_read_f32_at(None, 1, 1, 4, 4, 1, None, 8, None, None, None, None, None, 0, None, None, None, None) == -1
+    assert defs['RMNET_MR_QX'] == ops.MR_QX == defs['RMNET_BANK_QX'] == ops.BANK_QX
+    assert len({defs['RMNET_MR_FORCE_GENERIC'], defs['RMNET_MR_EXACT_FP32'], defs['RMNET_MR_F16'], defs['RMNET_MR_QX']}) == 4   # distinct bits
+    # RMNET_BANK_F16 and RMNET_BANK_QX are the only flags rmnet_bank_read_f32_at knows, and they exclude each other: an unknown bit (16)
+    # or both together are refused before any launch (with NULL pointers every call is refused anyway: tests/test_gpu_parity.py
+    # test_qx_mode_on_large_logits_and_flag_rules makes the same two calls with valid arguments on the GPU)
+    assert lib.rmnet_bank_read_f32_at(None, 1, 1, 4, 4, 1, None, 16, None, None, None, None, None, 0, None, None, None, None) == -1
+    assert lib.rmnet_bank_read_f32_at(None, 1, 1, 4, 4, 1, None, 4 | 8, None, None, None, None, None, 0, None, None, None, None) == -1
