@@ -111,12 +111,11 @@ def _median_time(fn, reps):
 def cpu_baseline(n_frames=3):
     """Oracle CPU path (plain torch + C ops, oracle/) timed on this box's host cores, bounded sample.
 
-    ``value`` = BASELINE.md section 3's CPU leg = BASELINE configs[0]: ONE synthetic 480x854 clip, 1 object, N = 4 frames,
-    memorize_every = 1 (the memory grows to T = 3), TinyFlowNet + the whole frame loop (``OracleRMNet.forward``), at the BEST
-    thread count of a sweep over {8, 16, 32, 64, 128} (those that the box has); the sweep is kept in ``sweep``.
-    Beside it, at the best thread count and at 8 threads: the GPU workload's own shape (memory PINNED at T = 5: 4 committed
-    frames pre-filled untimed, every timed frame = TinyFlowNet + memorize + cat -> T = 5 + warp / boxes + segment +
-    soft-max) and the three native ops alone."""
+    ``value`` = the TWIN of the GPU line's workload (BASELINE configs[1]'s shape): ONE 480x854 stream, 1 object, memory PINNED at
+    T = 5 (4 committed frames pre-filled untimed, every timed frame = TinyFlowNet + memorize + cat -> T = 5 + warp / boxes + segment +
+    soft-max), at the BEST thread count of a sweep over {8, 16, 32, 64, 128} (those that the box has).  The sweep itself runs
+    BASELINE.md section 3's CPU leg = BASELINE configs[0] (one clip, N = 4 frames, memorize_every = 1: the memory grows to T = 3,
+    TinyFlowNet + ``OracleRMNet.forward``) and is kept in ``configs0``; also: the three native ops alone."""
     import numpy as np
     import torch.nn.functional as F
     from oracle import oracle
@@ -203,16 +202,20 @@ def cpu_baseline(n_frames=3):
     ops['note'] = ('memory_read = models/rmnet.py:147-165 with torch CPU ops (the survey measured 0.28 s for the reference '
                    'itself on 8 vCPUs); region_map / flow_affine = oracle/rmnet_oracle.c (the reference runs flow_affine '
                    'single-threaded in DataLoader workers)')
-    return {'value': sweep[best], 'unit': 'frames/s', 'cores': best, 'threads_best': best, 'kind': 'port',
+    # `value` is the TWIN of the GPU line's workload (round-5 verdict): one 480x854 stream, 1 object, memory pinned at T = 5 -- the
+    # same frame the GPU times, on the host cores -- at the best thread count of the sweep.  BASELINE configs[0] (the reference's own
+    # CPU-runnable case: T grows to 3, N = 4) stays beside it.
+    return {'value': round(n_frames / dt_best, 4), 'unit': 'frames/s', 'cores': best, 'threads_best': best, 'kind': 'port',
             'host_threads_available': all_threads,
-            'sweep': {str(n): v for n, v in sweep.items()},
-            'value_8_threads': sweep[min(8, all_threads)],
-            'T5_pinned': {'fps_best_threads': round(n_frames / dt_best, 4), 'fps_8_threads': round(n_frames / dt8, 4),
-                          'note': 'the GPU workload\'s own shape on the CPU: memory pinned at T=%d (4 committed frames pre-filled untimed), '
-                                  '%d timed frames, TinyFlowNet included' % (T_MEM, n_frames)},
-            'sample': 'BASELINE configs[0] (BASELINE.md section 3): one synthetic 480x854 clip, 1 object, N=4 frames, memorize_every=1 '
-                      '(memory grows to T=3), TinyFlowNet + OracleRMNet.forward, fp32; best of two passes (3 segmented frames each) per '
-                      'thread count, warm-up of one frame per count; value = the best count of the sweep (cores = that count)',
+            'value_8_threads': round(n_frames / dt8, 4),
+            'sample': 'the GPU workload\'s own shape on the CPU (BASELINE configs[1]): one synthetic 480x854 stream, 1 object, memory PINNED at '
+                      'T=%d (4 committed frames pre-filled untimed), %d timed frames of TinyFlowNet + memorize + cat + warp / boxes + segment + '
+                      'soft-max (oracle.OracleRMNet, fp32), one warm-up frame; thread count = the best of the configs[0] sweep below' % (T_MEM, n_frames),
+            'configs0': {'fps_best_threads': sweep[best], 'fps_8_threads': sweep[min(8, all_threads)],
+                         'sweep': {str(n): v for n, v in sweep.items()},
+                         'note': 'BASELINE configs[0] (BASELINE.md section 3): one synthetic 480x854 clip, 1 object, N=4 frames, memorize_every=1 '
+                                 '(memory grows to T=3), TinyFlowNet + OracleRMNet.forward; best of two passes (3 segmented frames each) per thread '
+                                 'count, warm-up of one frame per count'},
             'ops': ops}
 
 
@@ -396,7 +399,7 @@ def main():
     ap.add_argument('--graph', action='store_true', help='replay the frame step as one captured HIP graph')
     ap.add_argument('--read-precision', choices=('auto', 'split', 'qx', 'f16'), default='auto',
                     help="arithmetic of the bank read in the timed region: 'auto' (default, = RMNet's default) picks 'f16' for clips with one "
-                         "object -- this workload -- and 'qx' for clips with several (profiles/r05_iou_calibration.md); 'split' = fp16 hi/lo "
+                         "object -- this workload -- while the clip's largest logit stays small, 'split' otherwise and for clips with several (profiles/r06_iou_temperature.md); 'split' = fp16 hi/lo "
                          "pairs, three MFMA terms, fp32-class; 'f16' = fp16 operands, one term; 'qx' = 'f16' with an exact query (two terms for "
                          "the logits).  The other modes' kernels are timed on the same launches after the timed region (roofline.modes)")
     ap.add_argument('--dist-backend', default=None, help="override the process-group backend ('gloo' lets several "
@@ -570,27 +573,41 @@ def main():
             net._profile_events = None
             other_ms[om] = [events.elapsed_ms(events.ev[3 * i], events.ev[3 * i + 2]) - 2e-3 * ev_floor_us for i in range(args.steps)]
         bank.precision = args.read_precision
-        # ... and the timed arithmetic at the launch size of rounds 1-4 (8 object-frames per launch: every pair is cut in two, the
-        # partial results are merged by the last arriver), inside the same loop on the first 8 clips (MIOpen immediate mode for these
-        # extra shapes: the read does not depend on the convolutions' algorithms, only on what they leave in the caches)
-        small_ms = None
-        if B > 8:
-            find = torch.backends.cudnn.benchmark
-            torch.backends.cudnn.benchmark = False
-            ctx8 = net._ClipContext(net, 8, K_CH, H, W, [K_CH - 1] * 8, dev)
-            bank8 = net.new_bank(ctx8, T_MEM)
-            f8, m8 = frames[:8], masks[:8]
-            for t in range(1, T_MEM):
-                net.frame_step(ctx8, bank8, f8[:, t - 1], m8[:, t - 1], f8[:, t], tfn._forward(f8[:, t], f8[:, t - 1]), commit=True)
-            for i in range(3 + args.steps):
-                t = T_MEM + (i % (n_clip - T_MEM))
-                net._profile_events = tuple(events.ev[3 * (i - 3):3 * (i - 3) + 3]) if i >= 3 else None
-                net.frame_step(ctx8, bank8, f8[:, t - 1], m8[:, t - 1], f8[:, t], tfn._forward(f8[:, t], f8[:, t - 1]), commit=False)
-            torch.cuda.synchronize()
-            net._profile_events = None
-            small_ms = [events.elapsed_ms(events.ev[3 * i], events.ev[3 * i + 2]) - 2e-3 * ev_floor_us for i in range(args.steps)]
-            torch.backends.cudnn.benchmark = find
-            del bank8, ctx8
+        # ... and the timed arithmetic at OTHER launch sizes (object-frames per launch = clips per GPU here), each inside the same frame
+        # loop on its own clips (MIOpen immediate mode for these extra shapes: the read does not depend on the convolutions'
+        # algorithms, only on what they leave in the caches).  1 = the reference's operating point (core/inference.py:22-28: one clip
+        # at a time); <= 8: every (object, query tile) pair is cut into column blocks and merged by its last arriver; 16: one workgroup
+        # per pair; > 19: more pairs than workgroups -- the launch runs in ROUNDS (csrc/common.h: bank_round_chunk_len).
+        small_ms = {}
+        find = torch.backends.cudnn.benchmark
+        torch.backends.cudnn.benchmark = False
+        k_small = min(args.steps, 10)
+        for n in (1, 4, 8, 12, 16, 20, 24, 32):
+            if n == B:
+                continue
+            try:
+                if n <= B:
+                    fn, mn = frames[:n], masks[:n]
+                else:
+                    extra = [synthetic_clip(n_clip, K_CH, H, W, seed=rank * 64 + c, size=2.1) for c in range(B, n)]
+                    fn = torch.cat([frames] + [c[0].to(dev) for c in extra])
+                    mn = torch.cat([masks] + [c[1].to(dev).float() for c in extra])
+                ctxn = net._ClipContext(net, n, K_CH, H, W, [K_CH - 1] * n, dev)
+                bankn = net.new_bank(ctxn, T_MEM, precision=args.read_precision)
+                for t in range(1, T_MEM):
+                    net.frame_step(ctxn, bankn, fn[:, t - 1], mn[:, t - 1], fn[:, t], tfn._forward(fn[:, t], fn[:, t - 1]), commit=True)
+                for i in range(3 + k_small):
+                    t = T_MEM + (i % (n_clip - T_MEM))
+                    net._profile_events = tuple(events.ev[3 * (i - 3):3 * (i - 3) + 3]) if i >= 3 else None
+                    net.frame_step(ctxn, bankn, fn[:, t - 1], mn[:, t - 1], fn[:, t], tfn._forward(fn[:, t], fn[:, t - 1]), commit=False)
+                torch.cuda.synchronize()
+                net._profile_events = None
+                small_ms[n] = [events.elapsed_ms(events.ev[3 * i], events.ev[3 * i + 2]) - 2e-3 * ev_floor_us for i in range(k_small)]
+                del bankn, ctxn, fn, mn
+            except RuntimeError as exc:      # (a secondary figure must not take the driver line down)
+                small_ms[n] = repr(exc)[:200]
+                torch.cuda.synchronize()
+        torch.backends.cudnn.benchmark = find
     main_raw = sum(main_ms) / len(main_ms)
     main_avg = max(main_raw - ev_floor_us * 1e-3, 1e-6)     # kernel time = bracket - empty-bracket floor
     abytes = algorithmic_bytes(B * (K_CH - 1), T_MEM, ctx.h, ctx.w)
@@ -626,6 +643,9 @@ def main():
         else:
             traffic_note = 'profiles/' + tname + ' is from other kernel sources or another workload: not reported'
 
+    from rmnet_amd import rmnet as _rmnet_mod
+    AUTO_BOUND = _rmnet_mod.AUTO_LOGIT_BOUND
+    logit_max = bank.logit_max()             # (one host sync, outside the timed region) the quantity 'auto' decides on
     extras = None
     if rank == 0 and world == 1 and not args.no_extras and not args.extras_child:
         # The extras (single stream, HIP-graph replay, free-running clip, other configurations, every kernel alone, profiler shares) run
@@ -821,7 +841,10 @@ def main():
                       'f16': 'f32 convs; memory read = fp16 operands (K, V, q, P rounded to 11 bits), fp32 accumulate (RMNET_BANK_F16): the frame '
                              'loop\'s default for clips with one object -- on one-object 480x854 clips whose masks HAVE a boundary (tests/live_fixture.py) '
                              'mask IoU vs the CPU path 0.99993-0.99997 and foreground logits within 1.3e-3 (an IoU loss of 1e-3 ~ 2e-2); the same comparison '
-                             'FAILS (0.9969) when the read-out is noised by 1 % (profiles/r05_iou_calibration.md, tests/test_gpu_parity.py)'}[args.read_precision],
+                             'FAILS (0.9969) when the read-out is noised by 1 % (profiles/r05_iou_calibration.md, tests/test_gpu_parity.py).  [r6] \'auto\' keeps '
+                             'it only while the largest affinity logit the bank has MEASURED on the clip stays below %.0f (this run: %.1f): with the key '
+                             'convolutions scaled until the soft-max is peaked (top-1 mass 0.5, logits ~150) f16 and qx fall to 0.9985-0.9990 and '
+                             'the clip is re-read in split (profiles/r06_iou_temperature.md)' % (AUTO_BOUND, logit_max)}[args.read_precision],
             'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: 480x854 synthetic clips, 1 object each (K=2), memory pinned '
                                    'at T=5, TinyFlowNet + memorize + regional read + decoder per frame; '
@@ -854,6 +877,11 @@ def main():
                                           '(profiles/r03_d_mfma_pmc.md): SQ_VALU_MFMA_BUSY_CYCLES = 87,336 cycles per SIMD per launch of the default mode = 47-50 % of '
                                           'the un-profiled launch (68 % during the tile walks), 26-27 % for the fp16-operand mode'},
                          'launches': args.steps,
+                         'auto_rule': {'requested': requested_precision, 'ran': args.read_precision, 'largest_logit_measured_by_the_bank': round(logit_max, 2),
+                                       'bound': AUTO_BOUND, 'several_objects': 'split',
+                                       'note': "read_precision='auto': one object per clip -> f16 while the bank's logit word (largest soft-max reference of "
+                                               "its reads, natural units) stays <= bound, else the clip is re-read in split; several objects -> split "
+                                               "(profiles/r06_iou_temperature.md, rmnet_amd/rmnet.py)"},
                          'avg_us': round(main_avg * 1e3, 2), 'avg_us_event_bracket': round(main_raw * 1e3, 2),
                          'event_floor_us': round(ev_floor_us, 2), 'min_us_event_bracket': round(min(main_ms) * 1e3, 2),
                          'op_avg_us': round((main_avg + comb_avg) * 1e3, 2), 'op_frac': round(op_achieved / HBM_PEAK_GBS, 4),
@@ -869,21 +897,29 @@ def main():
                 modes[om] = {'avg_us': round(o_us, 2), 'GBps': round(abytes / o_us / 1e3, 1), 'frac': round(abytes / o_us / 1e3 / HBM_PEAK_GBS, 4)}
             modes['note'] = ("the same launches (same bank, same boxes) in the three arithmetic modes of the kernel, whole read, HIP events on the "
                              "launch stream; the top-level figures are the timed region's mode ('%s').  split = fp32-class (error 1e-7); f16 = RMNET_BANK_F16: "
-                             "fp16 operands, fp32 accumulate, the loop's default for one object per clip (this workload); qx = RMNET_BANK_QX: f16 with an exact "
-                             "query, the loop's default for several objects per clip.  Whole-clip mask IoU vs the CPU path (profiles/r05_iou_calibration.md): "
+                             "fp16 operands, fp32 accumulate, the loop's default for one object per clip with small logits (this workload); qx = RMNET_BANK_QX: f16 with an exact "
+                             "query (opt-in); clips with several objects and clips with peaked soft-maxes are read in split.  Whole-clip mask IoU vs the CPU path (profiles/r05_iou_calibration.md): "
                              "one object, live mask boundaries: f16 0.99993-0.99997, qx / split / exact fp32 0.99999-1.00000; 3 / 5 objects: exact fp32 "
                              ">= 0.9997, qx >= 0.9993, f16 0.9986-0.9995" % args.read_precision)
             line['roofline']['modes'] = modes
-            if small_ms is not None:
-                s_us = 1e3 * sum(small_ms) / len(small_ms)
-                ab8 = algorithmic_bytes(8 * (K_CH - 1), T_MEM, ctx.h, ctx.w)
-                line['roofline']['launch_sizes'] = {
-                    str(B): {'object_frames': B, 'avg_us': round((main_avg + comb_avg) * 1e3, 2), 'frac': round(op_achieved / HBM_PEAK_GBS, 4)},
-                    '8': {'object_frames': 8, 'avg_us': round(s_us, 2), 'GBps': round(ab8 / s_us / 1e3, 1), 'frac': round(ab8 / s_us / 1e3 / HBM_PEAK_GBS, 4)},
-                    'note': 'the timed arithmetic at this run\'s launch size and at 8 object-frames per launch (the default of rounds 1-4), the '
-                            'latter inside the same frame loop on the first 8 clips.  At 16 every (object, query tile) pair is ONE workgroup that walks '
-                            'the pair\'s whole memory (208 workgroups, no partial results, no merge); at 8 every pair is cut in two and merged by its '
-                            'last arriver (DESIGN.md section 4 [r5])'}
+            if small_ms:
+                sizes = {str(B): {'object_frames': B, 'avg_us': round((main_avg + comb_avg) * 1e3, 2), 'frac': round(op_achieved / HBM_PEAK_GBS, 4),
+                                  'timed_region': True}}
+                for n, ms in small_ms.items():
+                    if isinstance(ms, str):
+                        sizes[str(n)] = {'object_frames': n, 'error': ms}
+                        continue
+                    n_us = 1e3 * sum(ms) / len(ms)
+                    abn = algorithmic_bytes(n * (K_CH - 1), T_MEM, ctx.h, ctx.w)
+                    sizes[str(n)] = {'object_frames': n, 'avg_us': round(n_us, 2), 'GBps': round(abn / n_us / 1e3, 1),
+                                     'frac': round(abn / n_us / 1e3 / HBM_PEAK_GBS, 4)}
+                sizes = {k: sizes[k] for k in sorted(sizes, key=int)}
+                sizes['note'] = ('the timed arithmetic (%s) at 1 ... 32 object-frames per launch (= clips per GPU at one object per clip), each inside the '
+                                 'frame loop on its own clips (%d launches; MIOpen immediate mode).  13 (object, query tile) pairs per object-frame on ~210 '
+                                 'computing workgroups: <= 12 object-frames: pairs cut into column blocks, merged by their last arriver; 16: one workgroup '
+                                 'per pair, no merge; >= 20: ROUNDS of aligned chunks -- whole objects first, the rest cut to fill one more round '
+                                 '(DESIGN.md section 4).  1 = the reference\'s operating point: one clip at a time' % (args.read_precision, min(args.steps, 10)))
+                line['roofline']['launch_sizes'] = sizes
         if extras is not None and extras.get('single_stream_fps'):
             line['config']['workload'] += ' -- value = %d clips batched per GPU; ONE 480p stream alone: %.1f frames/s' % (B, extras['single_stream_fps'])
         else:

@@ -25,11 +25,12 @@
 extern "C" {
 #endif
 
-#define RMNET_ABI_VERSION 5   /* 2: rmnet_bank_read_f32 takes a mutable bank; rmnet_bank_area_offset.  3: RMNET_MR_F16 / RMNET_BANK_F16,
+#define RMNET_ABI_VERSION 6   /* 2: rmnet_bank_read_f32 takes a mutable bank; rmnet_bank_area_offset.  3: RMNET_MR_F16 / RMNET_BANK_F16,
                                * rmnet_bank_read_f32_at takes flags.  4: banks of any Tcap, chunked reads of T > 2048 (rmnet_bank_read_workspace_bytes_for);
                                * the read counts out-of-window query elements; sticky error bits + time-out word behind the overflow word.
                                * 5: RMNET_MR_QX / RMNET_BANK_QX (fp16 operands with an exact query); a pair whose merge timed out is
-                               * written as NaN; the overflow word is a zero / non-zero flag, not an element count */
+                               * written as NaN; the overflow word is a zero / non-zero flag, not an element count.
+                               * 6: the bank keeps the largest affinity logit its reads have seen (third int32 of the control block) */
 
 enum {
   RMNET_OK = 0,
@@ -184,6 +185,12 @@ int rmnet_memory_read_f32_ev(const float *m_key, const float *m_val, const float
  *       merge gave up is written as NaN, never as a partially merged value).  Any non-zero value means: do not trust the reads of
  *       this bank, re-run exactly.  The word is a FLAG (zero / non-zero), not a count of elements: the read adds to it once per
  *       (query element, segment of the launch plan) that sees it, the append once per 16-byte group.
+ *       Logit word (ABI v6): the THIRD int32 of the control block (byte rmnet_bank_overflow_offset() + 8) holds, as float bits, the
+ *       largest soft-max reference max_j S_ij * log2(e) any read of this bank has used so far (sticky maximum over reads, queries and
+ *       objects; >= 0; the kernel's reference is deferred: the true maximum logit lies within 8 above value * ln 2).  The error of
+ *       RMNET_BANK_F16 / RMNET_BANK_QX grows with the logits (K and q are rounded to 11 bits: ~2^-11 |S| per logit), so a caller that
+ *       wants the fp32-class result on peaked soft-maxes checks this word once per clip and re-reads with flags = 0 when it is large
+ *       (rmnet_amd/rmnet.py does, bound and evidence: profiles/r06_iou_temperature.md).  Zero in a new bank.
  *       rmnet_bank_area_offset(): byte offset of the int32 [no][Tcap] table of cells stored per slot (accounting).
  *       One launch reads at most 2048 slots (LDS prefix arrays).  Longer memories (models/rmnet.py:416-426 has no bound; ABI v4):
  *       a bank may have any Tcap; rmnet_bank_read_f32 / _at with T > 2048 (host-side T only: T_dev must be NULL for such a bank)

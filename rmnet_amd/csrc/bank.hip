@@ -32,7 +32,9 @@
 //             and publish the fragments in LDS; 8 consumer waves accumulate O += V P for 64 value
 //             channels x all 64 queries each, with the V A-fragments loaded straight from the bank
 //             into registers (16 B / lane, no LDS, no transpose) one tile ahead, and feed the K
-//             ring.  ONE barrier per 32-cell tile.
+//             ring.  Split mode: ONE barrier per 32-cell tile, all waves in step.  fp16-operand modes [r6]:
+//             a step is 64 cells and TWO barrier intervals, the two consumers of a SIMD work half a step
+//             apart (one multiplies while the other loads) -- see the PING-PONG section below.
 //             The SAME launch also does everything else of MemoryReader.forward: while a workgroup waits for
 //             the first dependent loads of its plan it streams its share of the soft-max-independent
 //             outputs -- the q_val half of the cat (x box) and the read-out of MASKED query cells (= the
@@ -322,8 +324,7 @@ constexpr int kConsumers = 8;                              // waves 4-11
 constexpr int kCDT = kDo / 16 / kConsumers;                // d-tiles (16 value channels) per consumer: 4
 constexpr int kRThreads = 64 * (kProducers + kConsumers);  // 768 = 12 waves = 3 per SIMD
 constexpr int kProducerPrio = 2;   // static priority of the producer waves (s_setprio)
-constexpr int kSoftmaxInterleave = 6;   // fp16 modes, producers: soft-max VALU instructions scheduled between two S MFMAs
-constexpr int kPfSteps = 7;   // fp16 modes: L2 prefetch distance in steps of two tiles (L2Prefetch)
+constexpr int kPfStepsPP = 10;   // fp16 modes: L2 prefetch distance in steps of two tiles (L2Prefetch)
 
 // Workgroup = 12 waves (3 per SIMD), 64 compacted queries x one split of the tile list.
 //   waves 0-3  ("producers", static priority): S = K^T Q for 16 queries each (24 MFMAs per 32-cell
@@ -666,10 +667,14 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
     const char* nvh = b.vh + noff;
     const char* nvl = b.vl + noff;
     if (__any(al[0] != 1.0f || al[1] != 1.0f || al[2] != 1.0f || al[3] != 1.0f)) {
+      // (single v_mul_f32 on purpose, as in consumer_loop_pp: hipcc's packed v_pk_mul_f32 form of this rescale gave wrong read-outs
+      //  in the ping-pong walk's timing -- profiles/r06_a_pingpong_walk.md)
 #pragma unroll
       for (int dt = 0; dt < kCDT; ++dt)
 #pragma unroll
-        for (int it = 0; it < 4; ++it) acc[dt][it] *= al[it];
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(acc[dt][it][r]) : "v"(al[it]));
     }
     // ---- O += V P: 4 channel tiles x 4 query tiles x 3 split terms; the 4 query tiles between two
     //      uses of an accumulator keep the MFMAs independent
@@ -699,11 +704,11 @@ __device__ inline void consumer_loop(const BArgs& a, const Walk& wk, char* Kl_, 
 // convolutions between two reads stream hundreds of MB), a V fragment load is issued ONE step (~1.3 us) before its use and an
 // HBM miss under load takes longer than that: the tile walk then runs at memory latency, not at the matrix pipe's pace (measured
 // in the loop: 1.77 us per step against 1.30 with a warm cache).  The nqt workgroups of a column block walk the same K / V tiles
-// in lockstep on one XCD, i.e. behind one L2: each of them touches 1/nqt of the 128-byte lines of the step kPfSteps steps ahead
+// in lockstep on one XCD, i.e. behind one L2: each of them touches 1/nqt of the 128-byte lines of the step kPfStepsPP steps ahead
 // (one dword per line) so that the demand loads of all of them hit the L2.  The touch is an LDS-DMA load into a 256-byte junk
 // patch of the issuing wave: no destination register, nothing ever waits for it (hipcc does not see the load: its own counted
 // waits only get more conservative; __syncthreads() stays a bare barrier).  In the loop the producers issue it (one wave
-// instruction per step for the usual 12 query tiles); the first kPfSteps - 1 steps are touched by the CONSUMERS while they wait for
+// instruction per step for the usual 12 query tiles); the first kPfStepsPP - 1 steps are touched by the CONSUMERS while they wait for
 // the producers' first soft-max -- in the producers' own prologue those address computations sat on the critical path of the
 // whole workgroup.
 struct L2Prefetch {
@@ -749,37 +754,35 @@ struct L2Prefetch {
 };
 
 // ================================================================================================================
-// fp16-operand mode (RMNET_BANK_F16): hi planes only -- K, V, the query and P enter the MFMAs rounded to fp16 (11
-// significant bits), fp32 accumulate.  One MFMA term instead of three, and half the bank bytes.  The LDS slots and
-// registers that carry the lo planes in the split mode carry a SECOND memory tile here, so a barrier step covers
-// 64 memory cells (two tiles of the walk, which may belong to different frames).  With a third of the MFMA work
-// per cell the step is bound by latencies, not by the matrix pipe (trace: tools/bk_trace.py), so the pipeline is
-// one stage deeper than the split mode's and nobody starts an iteration with a round trip to LDS:
-//   producers (waves 0-3), iteration n: S(n+3) from fragments read one iteration ago (16 MFMAs, four chains);
-//              soft-max(n+2) -> P[(n+2) % 3]; fragments of K(n+4) from ring slot n % 4.  The soft-max denominator
-//              is the sum of the ROUNDED weights (an MFMA against an all-ones fragment), so the weights that
-//              multiply V sum to one exactly as normalised: a peaked soft-max returns its cell's value with V's
-//              rounding only.  The cell counts of a ragged step come from LDS one iteration ahead as well.
-//   consumers (waves 4-11), iteration n: O += V(n) P(n), 32 MFMAs, P(n) already in registers; V(n+1) bank ->
-//              registers behind each channel tile's MFMAs; P(n+1) (published an iteration ago, triple buffer)
-//              LDS -> registers behind the last channel tile; K(n+5) registers -> ring slot (n+1) % 4 and the
-//              request for K(n+6) (they wait at the barrier in this mode; the producers are the critical path).
-// Barriers: A (K steps 0..3 in the ring), B (P(0), P(1) published; ring slot 0 read), C (K step 4 in slot 0),
-// then one per step.
+// [r6] PING-PONG walk of the fp16-operand modes.  The lockstep walk above synchronises its 12 waves once per step and
+// every wave is in the same phase at the same time: both consumers of a SIMD issue their MFMAs together, then read
+// their P fragments together, then wait -- matrix pipe, L1 and LDS take turns instead of overlapping (3,350 cycles
+// per step for 1,312 of MFMA, 1,280 of L1 and ~600 of LDS; r05_g counters: pipe busy 28-32 %, waiting 46 %).
+// Here a step is TWO barrier intervals and the two consumers of a SIMD work half a step apart:
+//     interval E(n): group A (waves 4-7, channels 0-255)   O += V(n) P(n), 32 MFMAs, V(n+1) requested behind each channel tile
+//                    group B (waves 8-11, channels 256-511) "load phase": P(n) LDS -> registers, its share of K(n+6) -> ring,
+//                                                           K(n+7) requested, addresses of V(n+1)
+//     interval O(n): B   O += V(n) P(n);   A   load phase: P(n+1), K(n+6), K(n+7), addresses of V(n+2)
+// so the matrix pipe of a SIMD always has one consumer's 32 MFMAs (+ the producer's 8-10) while the other consumer's
+// LDS reads, ring stores and address arithmetic run in their shadow.  The producer's step is cut at the tile: per
+// interval it issues the 8 S MFMAs of ONE tile, re-reads that tile's fragment registers with the tile of the next
+// step (the LDS round trip flies under the rest of the interval instead of ending it) and does half of a soft-max:
+//     E(m): soft-max part 2 of step m+1 (exp2, round, publish P(m+1), denominator) | S of tile B of step m+2 | fragments A(m+3)
+//     O(m): S of tile A of step m+3 | fragments B(m+3) | soft-max part 1 of step m+2 (mask, row max, reference, alpha)
+// (ONE fragment register set: a k-step's two registers are re-read with the next tile right behind their last MFMA.)
+// Hand-offs (all by the one barrier between two intervals): P(s) is written in E(s-1), read by A in O(s-1) and by B in
+// E(s) (buffer s % 3); K(s) is stored in E/O(s-6), its tile A read in E(s-3), its tile B in O(s-3) (ring slot s & 3).
+// Barrier count per segment: A, B, 2 nst + 1 -- identical in all three roles (B runs A's loop one interval late).
 // ================================================================================================================
-// kQx (RMNET_BANK_QX) = the same walk with an EXACT QUERY: q enters the logits as a hi/lo pair -- the lo plane against the same K
-// fragments, 16 more MFMAs per step, producers only; K, P and V stay rounded to fp16.  The rounding of q is the one logit error
-// that is COHERENT over all memory cells of a query (K's roundings are independent from cell to cell and average out in the
-// weighted sum): on whole clips it is most of what the fp16-operand read costs in mask IoU (profiles/r05_iou_calibration.md).
 template <bool kQx>
-__device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
-                                         const int* tpre, const int* tarea, int wave, int lane,
-                                         float& m_out, float& l_out) {
+__device__ inline void producer_loop_pp(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
+                                        const int* tpre, const int* tarea, int wave, int lane,
+                                        float& m_out, float& l_out) {
   const BankView& b = a.b;
   const int o = wk.o;
   const int l15 = lane & 15, g = lane >> 4;
   const int jt0 = wk.jt0, ntl = wk.ntl;
-  const int nst = (ntl + 1) >> 1;                    // steps of two tiles (the last one may be half empty)
+  const int nst = (ntl + 1) >> 1;
   half8 qh[4], ql[kQx ? 4 : 1];
   {
     const int qn = wk.qt * kQT + wave * 16 + l15;
@@ -810,166 +813,202 @@ __device__ inline void producer_loop_f16(const BArgs& a, const Walk& wk, char* K
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (_Float16)1.0f;
 
+  // The L2 touches of the walk stay with the PRODUCERS (measured in a consumer's load phase, r6: an LDS-DMA load that misses to HBM
+  // sits in that wave's in-order vmcnt queue in front of its next V fragments and stalls the following PV phase by its whole
+  // latency; a producer never waits for a vector memory operation).
   L2Prefetch pf;
   pf.init(b, wk, tpre, Kl_, wave);
 
-  struct Frags { half8 a0[4], a1[4], b0[4], b1[4]; };   // tile A cells 0-15 / 16-31, tile B cells 0-15 / 16-31
-  auto k_frags = [&](Frags& f, int kslot) {             // 16 conflict-free ds_read_b128 (XOR-swizzled rows)
-    const char* kb = Kl_ + kslot * 2 * kKbuf;
+  struct Half { half8 r0[4], r1[4]; };                  // one tile: cells 0-15 / 16-31, four k-steps
+  auto k_half = [&](Half& f, int kslot, int plane) {    // 8 conflict-free ds_read_b128 (XOR-swizzled rows)
+    const char* kb = Kl_ + kslot * 2 * kKbuf + plane * kKbuf;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int sw = ((4 * ks + g) ^ l15) << 4;
-      f.a0[ks] = *reinterpret_cast<const half8*>(kb + l15 * 256 + sw);
-      f.a1[ks] = *reinterpret_cast<const half8*>(kb + (16 + l15) * 256 + sw);
-      f.b0[ks] = *reinterpret_cast<const half8*>(kb + kKbuf + l15 * 256 + sw);
-      f.b1[ks] = *reinterpret_cast<const half8*>(kb + kKbuf + (16 + l15) * 256 + sw);
+      f.r0[ks] = *reinterpret_cast<const half8*>(kb + l15 * 256 + sw);
+      f.r1[ks] = *reinterpret_cast<const half8*>(kb + (16 + l15) * 256 + sw);
     }
   };
-  struct S4 { f32x4 s[4]; };
-  auto s_mfma = [&](const Frags& f, S4& r) {         // four independent chains, interleaved
-#pragma unroll
-    for (int c = 0; c < 4; ++c) r.s[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (kQx) {                             // the query's lo plane first (small terms first)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        r.s[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a0[ks], ql[ks], r.s[0], 0, 0, 0);
-        r.s[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a1[ks], ql[ks], r.s[1], 0, 0, 0);
-        r.s[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.b0[ks], ql[ks], r.s[2], 0, 0, 0);
-        r.s[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.b1[ks], ql[ks], r.s[3], 0, 0, 0);
-      }
-    }
+  struct S2 { f32x4 s[2]; };                            // S of one tile: cells 4g + r / 16 + 4g + r of query l15
+  // S of one tile: two accumulator chains, interleaved (qx: the query's lo plane first at every k-step).  With kReload the two
+  // fragment registers of a k-step are re-read from (kslot, plane) right behind their last MFMA: the LDS round trip of the
+  // NEXT step's tile starts in the first half of the interval and never ends it.
+  auto s_half = [&](Half& f, S2& r, bool reload, int kslot, int plane) {
+    const char* kb = Kl_ + kslot * 2 * kKbuf + plane * kKbuf;
+    r.s[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    r.s[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      r.s[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a0[ks], qh[ks], r.s[0], 0, 0, 0);
-      r.s[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a1[ks], qh[ks], r.s[1], 0, 0, 0);
-      r.s[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.b0[ks], qh[ks], r.s[2], 0, 0, 0);
-      r.s[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.b1[ks], qh[ks], r.s[3], 0, 0, 0);
-    }
-  };
-  // nva / nvb = cells of the step's two tiles that exist (0 for a phantom tile past the split's end).  Its own basic
-  // block (wave-uniform branch), so that the rest of an iteration is ONE scheduling region.
-  auto mask_ragged = [&](S4& r, int nva, int nvb) {
-    if (nva < kJT || nvb < kJT) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        r.s[0][i] = (4 * g + i < nva) ? r.s[0][i] : -INFINITY;
-        r.s[1][i] = (16 + 4 * g + i < nva) ? r.s[1][i] : -INFINITY;
-        r.s[2][i] = (4 * g + i < nvb) ? r.s[2][i] : -INFINITY;
-        r.s[3][i] = (16 + 4 * g + i < nvb) ? r.s[3][i] : -INFINITY;
+      if constexpr (kQx) {
+        r.s[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.r0[ks], ql[ks], r.s[0], 0, 0, 0);
+        r.s[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.r1[ks], ql[ks], r.s[1], 0, 0, 0);
+      }
+      r.s[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.r0[ks], qh[ks], r.s[0], 0, 0, 0);
+      r.s[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.r1[ks], qh[ks], r.s[1], 0, 0, 0);
+      if (reload) {
+        const int sw = ((4 * ks + g) ^ l15) << 4;
+        f.r0[ks] = *reinterpret_cast<const half8*>(kb + l15 * 256 + sw);
+        f.r1[ks] = *reinterpret_cast<const half8*>(kb + (16 + l15) * 256 + sw);
       }
     }
   };
-  auto soft_max = [&](const S4& r, int pbuf) {
-    float sv[16];
+  // scheduling pattern of an interval's region: per k-step {MFMA, VALU x kV} x (2 or 4), then the two fragment reads
+  auto interleave = [&]() {
+    constexpr int kV = kQx ? 3 : 6;
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) sv[4 * c + i] = r.s[c][i];
-    float tmax = sv[0];
+      for (int i = 0; i < (kQx ? 4 : 2); ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, kV, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+  };
+  // soft-max, part 1: padding mask, row maximum, deferred reference, rescale factor.  Leaves nm = -reference (log2 domain)
+  // and alpha for part 2; the masked scores stay in sa / sb.
+  float nm = 0.0f, alpha = 1.0f;
+  auto soft_max1 = [&](S2& sa, S2& sb, int nva, int nvb) {
+    if (nva < kJT || nvb < kJT) {                       // (wave-uniform: its own basic block)
 #pragma unroll
-    for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, sv[e]);
+      for (int i = 0; i < 4; ++i) {
+        sa.s[0][i] = (4 * g + i < nva) ? sa.s[0][i] : -INFINITY;
+        sa.s[1][i] = (16 + 4 * g + i < nva) ? sa.s[1][i] : -INFINITY;
+        sb.s[0][i] = (4 * g + i < nvb) ? sb.s[0][i] : -INFINITY;
+        sb.s[1][i] = (16 + 4 * g + i < nvb) ? sb.s[1][i] : -INFINITY;
+      }
+    }
+    float tmax = fmaxf(fmaxf(fmaxf(sa.s[0][0], sa.s[0][1]), fmaxf(sa.s[0][2], sa.s[0][3])),
+                       fmaxf(fmaxf(sa.s[1][0], sa.s[1][1]), fmaxf(sa.s[1][2], sa.s[1][3])));
+    tmax = fmaxf(tmax, fmaxf(fmaxf(fmaxf(sb.s[0][0], sb.s[0][1]), fmaxf(sb.s[0][2], sb.s[0][3])),
+                             fmaxf(fmaxf(sb.s[1][0], sb.s[1][1]), fmaxf(sb.s[1][2], sb.s[1][3]))));
     tmax = group4_max(tmax);
     const bool bump = tmax > mref + kDeferRaw;
-    const float alpha = bump ? __builtin_amdgcn_exp2f((mref - tmax) * kSraw) : 1.0f;
+    alpha = bump ? __builtin_amdgcn_exp2f((mref - tmax) * kSraw) : 1.0f;
     mref = bump ? tmax : mref;
-    const float nm = -mref * kSraw;
+    nm = -mref * kSraw;
+  };
+  // soft-max, part 2: weights, rounding to fp16 (B-fragment layout of O = V P), publication, denominator (the sum of the
+  // ROUNDED weights: an MFMA against an all-ones fragment)
+  auto soft_max2 = [&](const S2& sa, const S2& sb, int pbuf) {
     u32x4 pa, pb_;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const half2 ha = {(_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sv[2 * i], kSraw, nm)),
-                        (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sv[2 * i + 1], kSraw, nm))};
-      const half2 hb = {(_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sv[8 + 2 * i], kSraw, nm)),
-                        (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sv[8 + 2 * i + 1], kSraw, nm))};
-      pa[i] = __builtin_bit_cast(unsigned, ha);
-      pb_[i] = __builtin_bit_cast(unsigned, hb);
+    for (int i = 0; i < 2; ++i) {
+      const half2 h0 = {(_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sa.s[0][2 * i], kSraw, nm)),
+                        (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sa.s[0][2 * i + 1], kSraw, nm))};
+      const half2 h1 = {(_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sa.s[1][2 * i], kSraw, nm)),
+                        (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sa.s[1][2 * i + 1], kSraw, nm))};
+      const half2 h2 = {(_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sb.s[0][2 * i], kSraw, nm)),
+                        (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sb.s[0][2 * i + 1], kSraw, nm))};
+      const half2 h3 = {(_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sb.s[1][2 * i], kSraw, nm)),
+                        (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sb.s[1][2 * i + 1], kSraw, nm))};
+      pa[i] = __builtin_bit_cast(unsigned, h0);
+      pa[2 + i] = __builtin_bit_cast(unsigned, h1);
+      pb_[i] = __builtin_bit_cast(unsigned, h2);
+      pb_[2 + i] = __builtin_bit_cast(unsigned, h3);
     }
     char* pb = Pl_ + pbuf * kPbuf + wave * 2048 + lane * 16;
     *reinterpret_cast<u32x4*>(pb) = pa;
     *reinterpret_cast<u32x4*>(pb + 1024) = pb_;
     if (g == 0) Al[pbuf * kQT + l15 * 4 + wave] = alpha;
-    // denominator: every row of ones x P is the column sum of the rounded weights of query l15
     f32x4 lc = {lsum * alpha, 0.f, 0.f, 0.f};
     lc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, __builtin_bit_cast(half8, pa), lc, 0, 0, 0);
     lc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, __builtin_bit_cast(half8, pb_), lc, 0, 0, 0);
     lsum = lc[0];
   };
-  Cursor cs;                       // walks ahead of the soft-max: the cell counts of a step are fetched an iteration early
+  // cell counts of a step (for the padding mask of a frame's last tile).  The cursor keeps the CURRENT frame's area in an SGPR: the
+  // LDS is read only when a frame ends, so the per-step look-up is scalar arithmetic (as a per-step LDS -> SGPR round trip it sat
+  // in the producers' O interval, the longest of the walk: r6 interval time line)
+  Cursor cs;
   cs.init(tpre, wk.t, jt0 + ntl - 1);
-  auto step_valid = [&](int step, int& nva, int& nvb) {
-    const int ja = jt0 + 2 * step;
-    const int la = cs.seek(ja);
-    nva = ja < jt0 + ntl ? tarea[cs.tt] - la * kJT : 0;
-    const int lb = cs.seek(ja + 1);
-    nvb = ja + 1 < jt0 + ntl ? tarea[cs.tt] - lb * kJT : 0;
+  int cs_area = __builtin_amdgcn_readfirstlane(tarea[wk.t]), cs_tt = wk.t;
+  auto valid_of = [&](int j) {                       // cells of tile j that exist (0 past the split's end)
+    const int l = cs.seek(j);
+    if (cs.tt != cs_tt) { cs_tt = cs.tt; cs_area = __builtin_amdgcn_readfirstlane(tarea[cs_tt]); }   // (wave-uniform; once per frame)
+    return j < jt0 + ntl ? cs_area - l * kJT : 0;
   };
-  S4 sp;                           // S of the step whose soft-max comes next
-  Frags f;
-  int nva, nvb;                    // cell counts of that step
-  int nva0, nvb0, nva1, nvb1;      // (steps 0 and 1: their LDS -> SGPR round trips are taken BEFORE barrier A, while the consumers'
-  step_valid(0, nva0, nvb0);       //  first K tiles are still on their way; between A and B this wave is the workgroup's critical path)
+  auto step_valid = [&](int step, int& nva, int& nvb) {
+    nva = valid_of(jt0 + 2 * step);
+    nvb = valid_of(jt0 + 2 * step + 1);
+  };
+  auto bar = [&]() {               // (LDS only crosses an interval boundary; the L2 touches are never waited for)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  int nva0, nvb0, nva1, nvb1, nva, nvb;
+  step_valid(0, nva0, nvb0);       // (LDS -> SGPR round trips taken while the consumers' first K tiles are on their way)
   step_valid(1, nva1, nvb1);
   step_valid(2, nva, nvb);
+  Half f;                          // ONE fragment set: it alternates between tile B of a step (read in O, used in E) and tile A of
+                                   // the next step (read in E, used in O) -- every register is re-read right behind its last MFMA
+  S2 ca, cb;                       // S of the step whose soft-max part 2 comes next (part 1 done)
+  S2 na, nb;                       // S of the step after it (tile A complete; tile B computed in E)
   __syncthreads();                                   // A: K steps 0..3 in the ring
   {
-    S4 s0, s1;
-    k_frags(f, 0);
-    s_mfma(f, s0);
-    k_frags(f, 1);
-    s_mfma(f, s1);
-    k_frags(f, 2);
-    s_mfma(f, sp);
-    mask_ragged(s0, nva0, nvb0);
-    soft_max(s0, 0);
-    mask_ragged(s1, nva1, nvb1);
-    soft_max(s1, 1);
-    k_frags(f, 3);
+    S2 s0a, s0b;
+    k_half(f, 0, 0);
+    s_half(f, s0a, true, 0, 1);                      // S(0) tile A; tile B of step 0 behind it
+    s_half(f, s0b, true, 1, 0);                      //      tile B; tile A of step 1
+    s_half(f, ca, true, 1, 1);                       // S(1)
+    s_half(f, cb, true, 2, 0);
+    soft_max1(s0a, s0b, nva0, nvb0);
+    soft_max2(s0a, s0b, 0);                          // P(0)
+    s_half(f, na, true, 2, 1);                       // S of tile A of step 2; tile B of step 2 behind it: E(0)
+    soft_max1(ca, cb, nva1, nvb1);                   // part 1 of step 1 (part 2: E(0))
   }
-  __syncthreads();                                   // B: P(0), P(1) visible; ring slot 0 free
-  __syncthreads();                                   // C: K step 4 in slot 0
-  int pbuf = 2;                                      // (n + 2) % 3
-  for (int n = 0; n < nst; ++n) {
-    mask_ragged(sp, nva, nvb);
+  __syncthreads();                                   // B: P(0) visible; ring slots 0, 1 free (K steps 4, 5 go there in E(0))
+  int pbuf = 1;                                      // (m + 1) % 3
+  // One step = E(m), O(m).  The three S register sets rotate (cur <- next <- new): the loop body is written three times with the
+  // names rotated instead of copying 24 registers per step.
+  S2 ta, tb;                       // third set (tile A of step m+3 lands in ta)
+  auto step_pair = [&](int m, S2& c_a, S2& c_b, S2& n_a, S2& n_b, S2& t_a) {
+    // ---- E(m)
     __builtin_amdgcn_sched_barrier(0);
-    S4 s0;
-    s_mfma(f, s0);                                   // step n+3
-    soft_max(sp, pbuf);                              // step n+2
-    // one S MFMA, then a few soft-max VALU instructions, and so on: issued back to back the 16 MFMAs of this wave wait
-    // for the pipe behind the consumers' (~40 cycles each, trace) while its VALU chain sits behind them in program order
-#pragma unroll
-    for (int i = 0; i < (kQx ? 32 : 16); ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, kQx ? (kSoftmaxInterleave + 1) / 2 : kSoftmaxInterleave, 0);
-    }
+    s_half(f, n_b, true, (m + 3) & 3, 0);            // S of tile B of step m+2; tile A of step m+3 behind it
+    soft_max2(c_a, c_b, pbuf);                       // step m+1 -> P(m+1)
+    interleave();
     __builtin_amdgcn_sched_barrier(0);
-    sp = s0;
-    k_frags(f, n & 3);                               // step n+4
-    step_valid(n + 3, nva, nvb);                     // (LDS round trips: they end under the barrier)
     pbuf = pbuf == 2 ? 0 : pbuf + 1;
-    pf.touch(n + kPfSteps, wave, kProducers, lane);
-    __syncthreads();
+    bar();
+    // ---- O(m)
+    s_half(f, t_a, true, (m + 3) & 3, 1);            // S of tile A of step m+3; tile B of step m+3 behind it
+    soft_max1(n_a, n_b, nva, nvb);                   // step m+2
+    interleave();
+    __builtin_amdgcn_sched_barrier(0);
+    step_valid(m + 3, nva, nvb);
+    pf.touch(m + kPfStepsPP, wave, kProducers, lane);
+    bar();
+  };
+  for (int m = 0; m < nst; m += 3) {
+    step_pair(m, ca, cb, na, nb, ta);
+    if (m + 1 >= nst) break;
+    step_pair(m + 1, na, nb, ta, tb, ca);
+    if (m + 2 >= nst) break;
+    step_pair(m + 2, ta, tb, ca, cb, na);
   }
+  bar();                                             // (the consumers' last interval)
   m_out = mref * kSraw;
   l_out = lsum;
   query_range_check(b, qh, wk.qt * kQT + wave * 16 + l15 < wk.Mq);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the patch is free again; the youngest touch is kPfSteps steps old)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the prefetch patch is free again)
 }
 
-__device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
-                                         const int* tpre, int wave, int lane,
-                                         f32x4 (&acc)[kCDT][4]) {
+__device__ inline void consumer_loop_pp(const BArgs& a, const Walk& wk, char* Kl_, char* Pl_, float* Al,
+                                        const int* tpre, int wave, int lane,
+                                        f32x4 (&acc)[kCDT][4]) {
   const BankView& b = a.b;
   const int o = wk.o;
   const int l15 = lane & 15;
   const int jt0 = wk.jt0, ntl = wk.ntl;
   const int nst = (ntl + 1) >> 1;
+  const bool late = wave >= kProducers + kConsumers / 2;   // group B: one interval behind group A (wave-uniform)
   const size_t so0 = (size_t)o * b.Tcap;
   const size_t tiles_per_slot = (size_t)(b.hwp / kJT);
   const int dt0 = kCDT * (wave - kProducers);
   const size_t vlane = (size_t)(dt0 * 64 + lane) * 16;
   auto v_tile = [&](int tt, int ll) { return ((so0 + tt) * tiles_per_slot + ll) * (size_t)(kDo * kJT * 2) + vlane; };
-  // K ring: ring slot = step & 3; plane 0 of a slot = the step's first tile, plane 1 = its second tile (hi planes
-  // both).  A tile is one contiguous 8 KB block = 512 chunks of 16 B; consumer thread ct moves chunk ct of both
-  // tiles.  LDS image as in the split mode: row = cell (256 B), chunk c of row r stored at chunk c ^ (r & 15).
+  // K ring as in the lockstep walk: slot = step & 3, plane = tile of the step; consumer thread ct moves chunk ct of both tiles
   const int ct = (wave - kProducers) * 64 + lane;
   const int crow = ct >> 4;
   const int kdst = crow * 256 + (((ct & 15) ^ (crow & 15)) << 4);
@@ -986,14 +1025,15 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
     *reinterpret_cast<half8*>(d) = kr[0];
     *reinterpret_cast<half8*>(d + kKbuf) = kr[1];
   };
-  half8 kr[2];                     // the step on its way to the ring (one iteration to land)
+  half8 k4[2], k5[2], kr[2];       // K steps 4, 5 (stored behind barrier B) and the step on its way to the ring
   {
     half8 k0[2], k1[2], k2[2], k3[2];
     k_load(k0, 0);
     k_load(k1, 1);
     k_load(k2, 2);
     k_load(k3, 3);
-    k_load(kr, 4);
+    k_load(k4, 4);
+    k_load(k5, 5);
     k_store(k0, 0);
     k_store(k1, 1);
     k_store(k2, 2);
@@ -1017,7 +1057,7 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
   for (int dt = 0; dt < kCDT; ++dt)
 #pragma unroll
     for (int it = 0; it < 4; ++it) acc[dt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
-  half8 pa[4], pb[4];              // P fragments of the current step
+  half8 pa[4], pb[4];              // P fragments of the step this wave multiplies next
   f32x4 al;                        // its rescale factors
   auto p_frags = [&](int buf) {
     const char* pfr = Pl_ + buf * kPbuf;
@@ -1028,36 +1068,60 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
       pb[it] = *reinterpret_cast<const half8*>(pfr + it * 2048 + 1024 + lane * 16);
     }
   };
-  __syncthreads();                                   // A: K steps 0..3 in the ring
-  {                                       // (idle until B: the producers compute S(0..2), P(0), P(1))
-    L2Prefetch pf;
-    pf.init(b, wk, tpre, Kl_, wave);
-#pragma unroll 1
-    for (int s_ = 1; s_ < kPfSteps; ++s_) pf.touch(s_, wave - kProducers, kConsumers, lane);   // (step 0 and the K tiles of steps 1..4 are demand loads)
-  }
-  __syncthreads();                                   // B: P(0), P(1) visible; ring slot 0 free
-  k_store(kr, 0);                                    // step 4
-  k_load(kr, 5);
-  p_frags(0);
-  __syncthreads();                                   // C
-  int pnext = 1;                                     // (n + 1) % 3
-  // addresses of the NEXT step's V tiles: found before the barrier, so that an iteration starts with MFMAs
-  const char *nva, *nvb;
+  auto bar = [&]() {               // LDS crosses an interval boundary, the V / K requests stay in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  const char *nva, *nvb;           // addresses of the NEXT step's V tiles (found in the load phase)
   auto v_next = [&](int step) {
     const int la = cv.seek(jt0 + 2 * step);          // (clamped past the end)
     nva = b.vh + v_tile(cv.tt, la);
     const int lb = cv.seek(jt0 + 2 * step + 1);
     nvb = b.vh + v_tile(cv.tt, lb);
   };
-  v_next(1);
+  int kstep = 6;                   // K step stored in this wave's next load phase (ring slot kstep & 3); kstep + 1 is requested there
+  int pb3 = 0;                     // pstep % 3 of the next load phase
+  auto load_phase = [&](int pstep) {                 // pstep: the step this wave multiplies next
+    p_frags(pb3);
+    pb3 = pb3 == 2 ? 0 : pb3 + 1;
+    k_store(kr, kstep & 3);
+    ++kstep;
+    k_load(kr, kstep);
+    v_next(pstep + 1);
+  };
+  __syncthreads();                                   // A: K steps 0..3 in the ring
+  k_load(kr, 6);
+  {                                                  // (idle until B: the producers compute S(0..2), P(0))
+    L2Prefetch pf;
+    pf.init(b, wk, tpre, Kl_, wave);
+#pragma unroll 1
+    for (int s_ = 1; s_ < kPfStepsPP; ++s_) pf.touch(s_, wave - kProducers, kConsumers, lane);
+  }
+  __syncthreads();                                   // B: P(0) visible; ring slots 0, 1 free
+  k_store(k4, 0);                                    // visible before O(0), where the producers read tile A of step 4
+  k_store(k5, 1);
+  if (late) {                                        // group B: E(0) is a load phase
+    load_phase(0);
+    bar();
+  } else {
+    p_frags(0);
+    pb3 = 1;
+    v_next(1);
+  }
   for (int n = 0; n < nst; ++n) {
-    k_store(kr, (n + 1) & 3);                        // step n+5 (its slot was last read in iteration n-3)
-    k_load(kr, n + 6);
+    // ---- O += V(n) P(n)
     if (__any(al[0] != 1.0f || al[1] != 1.0f || al[2] != 1.0f || al[3] != 1.0f)) {
+      // (single v_mul_f32 on purpose: as `acc[dt][it] *= al[it]` hipcc packs the 64 multiplies into v_pk_mul_f32 with op_sel, and in
+      //  this walk the read-out of 16 queries x one channel row then came out wrong in ~9 of 10 reads of tests/stress_race.py's 8-object
+      //  case -- always the low halves of the `it = 1` pairs of one accumulator, lanes 48-63; with plain multiplies 0 of 8.
+      //  profiles/r06_a_pingpong_walk.md has the bisect.  The packed form is also the slower one beside MFMAs: MI355X_MICROARCH.md)
 #pragma unroll
       for (int dt = 0; dt < kCDT; ++dt)
 #pragma unroll
-        for (int it = 0; it < 4; ++it) acc[dt][it] *= al[it];
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(acc[dt][it][r]) : "v"(al[it]));
     }
 #pragma unroll
     for (int dt = 0; dt < kCDT; ++dt) {
@@ -1071,11 +1135,12 @@ __device__ inline void consumer_loop_f16(const BArgs& a, const Walk& wk, char* K
       vb[dt] = *reinterpret_cast<const half8*>(nvb + dt * 1024);
       __builtin_amdgcn_sched_barrier(0);
     }
-    p_frags(pnext);                                  // step n+1: published an iteration ago; lands under the barrier
-    pnext = pnext == 2 ? 0 : pnext + 1;
-    v_next(n + 2);
-    __syncthreads();
+    bar();
+    // ---- load phase for step n+1 (under the other group's MFMAs)
+    load_phase(n + 1);
+    bar();
   }
+  if (!late) bar();                                  // (group B's last load phase)
 }
 
 constexpr int kMaxObj = kBankMaxObj;    // objects planned together in one launch (the launcher groups more)
@@ -1142,7 +1207,8 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
   __shared__ int o_njt[kMaxObj], o_m[kMaxObj], o_nqt[kMaxObj], o_cb[kMaxObj], o_sb[kMaxObj];
   __shared__ int o_rect[kMaxObj][4];
-  __shared__ int plan_n, plan_c, plan_own, sflag, sgave;
+  __shared__ int plan_n, plan_c, plan_own, plan_g, sflag, sgave;
+  __shared__ int o_c[kMaxObj];                      // chunk length of each object (one value for the launch unless it runs in rounds)
   char* Kl_ = lds;                                 // [ring slot][plane][8 KB]
   char* Pl_ = lds + 8 * kKbuf;                     // [buf][ntile][plane][lane*16]
   float* Al = reinterpret_cast<float*>(Pl_ + 3 * kPbuf);
@@ -1165,6 +1231,9 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   int spec_ar = 0;
   if (a.nobj <= kProducers + kConsumers && wave < a.nobj && lane0 < a.Tmax)
     spec_ar = b.area[(size_t)(a.obj0 + wave) * b.Tcap + lane0];
+  // [r6] the bank's sticky "largest affinity logit so far" word (below): requested here with the other early loads, compared after
+  // the walk -- a stale value only costs a redundant atomic
+  const int smax_seen = __hip_atomic_load(b.ovf + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int T_raw = a.T + (a.T_dev ? __builtin_amdgcn_readfirstlane(*a.T_dev) : 0);
   const int T_ = min(max(T_raw, 1), a.Tmax);         // memorised frames to read (the clamp is memory safety only:
   if (T_raw != T_ && blockIdx.x == 0 && tid == 0) atomicOr(b.ovf, kBankBadSlot);   // an out-of-range count is flagged)
@@ -1263,31 +1332,38 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
       if (ceq) { C0 = ceq; blocks = 2; }
     }
     if (!blocks && wave_sum_fast(bank_chunks(nqt, njt, C0, kSC, 1).nch) <= target) blocks = 1;   // short objects as blocks of their own (common.h)
-    const BankChunks bc0 = bank_chunks(nqt, njt, C0, kSC, blocks);
-    const int my_ch = bc0.nch, my_sl = bc0.nch + (bc0.R > 0 ? nqt : 0);   // chunks; slots (a remainder chunk can add one per query tile)
+    // [r6] more pairs than workgroups: ROUNDS of aligned chunks (common.h: bank_round_chunk_len) -- every object gets its own chunk
+    // length, every chunk is one segment, a workgroup runs chunk c, c + G, c + 2 G, ...
+    int Cobj = C0;
+    const int nqe = njt > 0 ? nqt : 0;
+    const int P = wave_sum_fast(nqe);
+    if (P > target) {
+      const int ps = wave_scan_incl_fast(nqe);
+      const int Pw = wave_max_fast(ps <= plan_div(P, target) * target ? ps : 0);
+      Cobj = bank_round_chunk_len(njt, ps, P, Pw, target, kCq);
+      blocks = 2;
+    }
+    const BankChunks bc0 = bank_chunks(nqt, njt, Cobj, kSC, blocks);
+    // chunks; partial slots (a remainder chunk can add one per query tile; an object that is ONE column block publishes nothing)
+    const int my_ch = bc0.nch, my_sl = (P > target && bc0.nfull <= 1) ? 0 : bc0.nch + (bc0.R > 0 ? nqt : 0);
     const int nch = wave_scan_incl_fast(my_ch), nsl = wave_scan_incl_fast(my_sl);
-    if (tid < ng) { o_cb[tid] = nch - my_ch; o_sb[tid] = nsl - my_sl; }
-    if (tid == RMNET_WAVE - 1) { plan_n = nch; plan_c = bc0.C; plan_own = blocks; }
+    if (tid < ng) { o_cb[tid] = nch - my_ch; o_sb[tid] = nsl - my_sl; o_c[tid] = Cobj; }
+    if (tid == RMNET_WAVE - 1) { plan_n = nch; plan_c = C0; plan_own = blocks; plan_g = target; }
   }
   __syncthreads();
   auto sld = [](const int& x) { return __builtin_amdgcn_readfirstlane(x); };   // LDS value -> SGPR
-  const int nchunks = sld(plan_n), C = sld(plan_c);
+  const int nchunks = sld(plan_n), G = min(sld(plan_g), nchunks);   // chunks of the launch; workgroups that compute (the others: static part)
   if ((int)blockIdx.x < ng && tid == 0) {   // plan record of object blockIdx.x (tools / debugging only)
     const int og = blockIdx.x;
     int32_t* pr = a.ws_plan + (size_t)(a.obj0 + og) * kPlanInts;
     const Rect r{o_rect[og][0], o_rect[og][1], o_rect[og][2], o_rect[og][3]};
     pr[0] = r.area(); pr[1] = o_nqt[og]; pr[2] = o_njt[og]; pr[3] = o_m[og];
     pr[4] = r.cx0; pr[5] = r.cx1; pr[6] = r.cy0; pr[7] = r.cy1;
-    pr[8] = a.slot0 + o_sb[og]; pr[9] = C; pr[10] = 0; pr[11] = 1;
+    pr[8] = a.slot0 + o_sb[og]; pr[9] = o_c[og]; pr[10] = nchunks; pr[11] = 1;
   }
 
   // =========================================== compute: this workgroup's chunk ===========================================
-  auto compute = [&]() {
-  int c;
-  {
-    const int q8 = nchunks >> 3, r8 = nchunks & 7, x = blockIdx.x & 7;   // XCD-contiguous logical ids
-    c = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (blockIdx.x >> 3);
-  }
+  auto compute = [&](const int c) {
   // object of chunk c = the last one whose chunk base is <= c (objects without chunks share the next one's base: the later one
   // wins); lane i looks at object i, and the nine plan values of the object travel LDS -> registers -> SGPRs in ONE round trip
   // (a serial search + a dozen dependent LDS reads cost ~1 us here)
@@ -1295,11 +1371,12 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   const bool lv = li < ng;
   const int v_cb = lv ? o_cb[li] : 0x7fffffff, v_nqt = lv ? o_nqt[li] : 0, v_njt = lv ? o_njt[li] : 0, v_sb = lv ? o_sb[li] : 0;
   const int v_m = lv ? o_m[li] : 0, v_r0 = lv ? o_rect[li][0] : 0, v_r1 = lv ? o_rect[li][1] : 0, v_r2 = lv ? o_rect[li][2] : 0;
-  const int v_r3 = lv ? o_rect[li][3] : 0;
+  const int v_r3 = lv ? o_rect[li][3] : 0, v_c = lv ? o_c[li] : 1;
   const unsigned long long le = __ballot(v_cb <= c);
   const int og = le ? 63 - __builtin_clzll(le) : 0;
   auto pick = [&](int v) { return __builtin_amdgcn_readlane(v, og); };
   const int nqt = pick(v_nqt), njt = pick(v_njt);
+  const int C = pick(v_c);                  // this object's chunk length
   const BankChunks bc = bank_chunks(nqt, njt, C, seg_cost_of(kTerms), sld(plan_own));
   const int cl = c - pick(v_cb);            // chunk inside the object
   const int lane = tid & 63;
@@ -1351,9 +1428,9 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     float m_seg = 0.0f, l_seg = 0.0f;   // producers: running reference (log2 domain) and sum of query 16 * wave + l15
     if constexpr (kTerms != 3) {          // 1: fp16 operands, 2: the same with an exact query -- one pipeline
       if (producer)
-        producer_loop_f16<kTerms == 2>(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, ln, m_seg, l_seg);
+        producer_loop_pp<kTerms == 2>(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, ln, m_seg, l_seg);
       else
-        consumer_loop_f16(a, wk, Kl_, Pl_, Al, tpre, wave, ln, acc);
+        consumer_loop_pp(a, wk, Kl_, Pl_, Al, tpre, wave, ln, acc);
     } else {
       if (producer)
         producer_loop(a, wk, Kl_, Pl_, Al, tpre, tarea, wave, ln, m_seg, l_seg);
@@ -1361,6 +1438,16 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
         consumer_loop(a, wk, Kl_, Pl_, Al, tpre, wave, ln, acc);
     }
 
+    // [r6] Largest soft-max reference of the segment's queries -> the bank's logit word (ovf[2], float bits, log2 domain, sticky
+    // maximum; rmnet_hip.h).  The fp16-operand arithmetics are accurate while the logits are small (the rounding of K and q costs
+    // ~2^-11 |S| per logit): the frame loop reads this word once per clip and re-reads the clip in the split arithmetic when it is
+    // beyond the calibrated bound (rmnet_amd/rmnet.py 'auto'; profiles/r06_iou_temperature.md).  m_seg is the DEFERRED reference:
+    // within 8 (natural units) below the true maximum.  Positive floats order like their bit patterns; in steady state the
+    // maximum is already there and no atomic is issued.
+    if (producer) {
+      const int bits = wave_max_fast(__float_as_int(fmaxf(m_seg, 0.0f)));
+      if (ln == 0 && bits > smax_seen) __hip_atomic_fetch_max(b.ovf + 2, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // ================= segment epilogue (all 12 waves; every barrier below is reached by all of them) =================
     const int l15 = ln & 15, g = ln >> 4;
     const PairSlots ps = pair_slots(slot_obj, nqt, bc, wk.qt);
@@ -1610,8 +1697,16 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     run_segment(bc.nfull + cr - plan_div(qt * span, C));
   }
   };   // compute()
-  if ((int)blockIdx.x < nchunks) {
-    compute();
+  if ((int)blockIdx.x < G) {
+    int c0;
+    {
+      const int q8 = G >> 3, r8 = G & 7, x = blockIdx.x & 7;             // XCD-contiguous logical ids
+      c0 = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (blockIdx.x >> 3);
+    }
+    for (int c = c0; c < nchunks; c += G) {                               // (one chunk unless the launch runs in rounds)
+      if (c != c0) __syncthreads();   // the previous chunk's LDS (tile prefix, K ring, P, alpha, epilogue scratch) is free
+      compute(c);
+    }
   }
 
   // =========================================== static part: drain the queue ===========================================

@@ -160,7 +160,7 @@ struct BankView {
   int32_t* area;   // [no][Tcap] cells inside the box of each memorised frame
   int32_t* ovf;    // control block (256 B): [0] number of 16-byte groups written (or query elements read) so far that held an element
                    // outside fp16's window, plus the sticky error bits 1 << 30 (slot / frame count out of range) and 1 << 29 (a merge
-                   // timed out); [1] merges that timed out; [16] the read kernel's static work queue (next item).  Bytes 64.. (queue words, arrival counters) are cleared by the launcher before every read
+                   // timed out); [1] merges that timed out; [2] largest soft-max reference of any read so far (float bits, log2 domain, >= 0); [16] the read kernel's static work queue (next item).  Bytes 64.. (queue words, arrival counters) are cleared by the launcher before every read
   int32_t* cnt;    // [no][nqt_max][2] (arrived, done) counters of the partials of an (object, query tile) pair
                    // (all queue words and counters are zero between reads)
   int no, Tcap, h, w, hw, hwp;
@@ -282,6 +282,26 @@ __host__ __device__ inline void bank_block_range(const BankChunks& k, int njt, i
     n = k.Cb;
   }
 }
+// [r6] ROUNDS: a launch with more (object, query tile) pairs than workgroups.  Cutting the work evenly there means chunks that cross
+// pair boundaries at shifted positions -- every workgroup streams its own copy of the K / V tiles and an XCD's L2 holds four objects
+// at once (measured, 20 / 24 / 32 object-frames: 0.39 / 0.42 / 0.49 of the roof against 0.65 at 16).  Instead the workgroups run
+// ROUNDS of aligned chunks: with P pairs on G workgroups, the first objects -- as many as fill R = P / G whole rounds -- are walked as
+// ONE column block each (nqt workgroups in lockstep on one XCD, no partial results, no merge); the objects behind them are cut into b
+// equal column blocks so that their chunks fill (at most) one more round.  Chunk c of the launch runs in round c / G on workgroup
+// c % G.  The chunk length of the object whose inclusive pair prefix is ps (pairs of this and all earlier objects):
+__host__ __device__ inline int bank_round_chunk_len(int njt, int ps, int P, int Pw, int G, int cq) {
+  const int R = plan_div(P, G);
+  if (njt <= 0 || ps <= R * G) return njt > 0 ? njt : 1;           // a whole object (Pw = the largest such prefix)
+  const int Pr = P - Pw;                                            // pairs of the objects behind the whole rounds (0 < Pr < 2 G)
+  int nb = Pr > 0 ? plan_div(G, Pr) : 1;                            // column blocks per pair that still fit one round
+  if (nb > plan_div(njt, kSplitMinTiles)) nb = plan_div(njt, kSplitMinTiles);
+  if (nb > kSplitMax - 4) nb = kSplitMax - 4;
+  if (nb < 1) nb = 1;
+  int c = plan_div(njt + nb - 1, nb);
+  c = plan_div(c + cq - 1, cq) * cq;                                // (fp16 modes: a step is two tiles)
+  return c > 0 ? c : 1;
+}
+
 // Smallest chunk length a launch may use: a chunk must amortise its prologue and 128 KB partial
 // (kSplitMinTiles), and a pair may have at most kSplitMax partials (combine's LDS).
 __host__ __device__ inline int bank_chunk_min(int njt_max) {

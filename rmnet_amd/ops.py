@@ -244,6 +244,19 @@ class MemoryBank:
         off = _lib.load().rmnet_bank_overflow_offset(self.no, self.capacity, self.h, self.w)
         return int(self.blob[off + 4:off + 8].view(torch.int32).item())
 
+    def status(self):
+        """(overflow word, merge time-outs, largest logit so far) in ONE device-to-host copy -- what the frame loop checks once per clip."""
+        off = _lib.load().rmnet_bank_overflow_offset(self.no, self.capacity, self.h, self.w)
+        w = self.blob[off:off + 12].cpu()
+        return int(w[0:4].view(torch.int32).item()), int(w[4:8].view(torch.int32).item()), float(w[8:12].view(torch.float32).item()) * 0.6931471805599453
+
+    def logit_max(self):
+        """Largest affinity logit (natural units, S = k . q / sqrt(128): models/rmnet.py:155-157) any read of this bank has used as a
+        soft-max reference so far -- the kernel's deferred reference, i.e. a lower bound within 8 of the true maximum (include/rmnet_hip.h,
+        "logit word").  Synchronises the stream: once per clip."""
+        off = _lib.load().rmnet_bank_overflow_offset(self.no, self.capacity, self.h, self.w)
+        return float(self.blob[off + 8:off + 12].view(torch.float32).item()) * 0.6931471805599453
+
     def assert_synced(self):
         """Debug aid: the host mirror ``committed`` and the device counter ``n_dev`` agree (they only move together in
         ``commit``; a captured ``frame_step(commit=True)`` or a foreign write to either would desynchronise them silently --
@@ -326,6 +339,9 @@ class TensorBank:
             self.m_key = torch.zeros(self.no, 128, self.capacity, self.h, self.w, device=self.device)
             self.m_val = torch.zeros(self.no, 512, self.capacity, self.h, self.w, device=self.device)
             self.rects = torch.zeros(self.no, self.capacity, 4, dtype=torch.int32, device=self.device)
+            # the whole-grid rectangle, built ONCE (a torch.tensor([...], device=...) per call is a blocking host-to-device copy
+            # in the middle of the frame loop: this is the overflow fallback of every clip)
+            self._full = torch.tensor([[0, self.w - 1, 0, self.h - 1]] * self.no, dtype=torch.int32, device=self.device)
         self.committed = 0
 
     def append(self, slot, k4, v4, rects=None):
@@ -333,13 +349,17 @@ class TensorBank:
         _check(v4, 'v4')
         self.m_key[:, :, slot] = k4
         self.m_val[:, :, slot] = v4
-        if rects is None:
-            self.rects[:, slot] = torch.tensor([0, self.w - 1, 0, self.h - 1], dtype=torch.int32, device=self.device)
-        else:
-            self.rects[:, slot] = rects.view(self.no, 4)
+        self.rects[:, slot] = self._full if rects is None else rects.view(self.no, 4)
 
     def overflow_count(self):
         return 0
+
+    def logit_max(self):
+        """(MemoryBank's interface: the exact-fp32 kernels have no arithmetic whose error grows with the logits.)"""
+        return 0.0
+
+    def status(self):
+        return 0, 0, 0.0
 
     def timeout_count(self):
         """(MemoryBank's interface: the exact-fp32 kernels have no cross-workgroup merge that could time out.)"""
@@ -362,7 +382,7 @@ class TensorBank:
 
     def read(self, T, q_key, q_val, qry_rects=None, out=None, events=None, ws=None):
         if qry_rects is None:
-            qry_rects = torch.tensor([[0, self.w - 1, 0, self.h - 1]] * self.no, dtype=torch.int32, device=self.device)
+            qry_rects = self._full
         out, _ = memory_read(self.m_key, self.m_val, q_key, q_val, self.rects[:, :T].contiguous(),
                              qry_rects.contiguous(), T=T, out=out, events=events,
                              flags=MR_EXACT_FP32 if T <= BANK_MAX_SLOTS else self._generic_flags(T))

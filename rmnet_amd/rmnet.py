@@ -58,6 +58,13 @@ class MemoryReader(nn.Module):
                                flags=ops._PRECISION_FLAGS[self.precision])
 
 
+# 'auto' read precision: the largest affinity logit (natural units; the bank's deferred soft-max reference, i.e. up to 8 below the true
+# maximum) up to which a one-object clip stays in the fp16-operand arithmetic.  Calibrated by the key-temperature sweep
+# (profiles/r06_iou_temperature.md): at |S| <= ~10 'f16' is at 0.9999+ of the CPU path's masks, at ~35 it is at 0.9994-0.9999, at ~150 below
+# the 0.999 bar.
+AUTO_LOGIT_BOUND = 12.0
+
+
 class RMNet(nn.Module):
     """INFERENCE ONLY.  The memory read, the bank, the box masking and the fused decoder tail are raw
     HIP kernels without autograd: ``forward`` / ``frame_step`` / ``segment`` / ``memorize`` run under
@@ -70,17 +77,17 @@ class RMNet(nn.Module):
         # arithmetic of the bank read in the frame loop:
         #   'split' = fp16 hi/lo pairs, three MFMA terms, fp32-class accuracy (1e-7) -- what rounds 1-3 ran everywhere;
         #   'f16'   = fp16 operands (K, q, P, V rounded to 11 bits), fp32 accumulate, 1.7x as fast;
-        #   'qx'    = 'f16' with the QUERY as a hi/lo pair (two terms for the logits): the rounding of q shifts all logits of a
-        #             query coherently and is most of what 'f16' costs on whole clips; 3 % slower than 'f16' in the frame loop;
-        #   'auto' (default) = 'f16' for clips with ONE object, 'qx' for clips with several.
-        # The task's bar is mask IoU within 1e-3 of the CPU path.  Calibrated against that path on the GPU
-        # (profiles/r05_iou_calibration.md; asserted by tests/test_gpu_parity.py) with the procedural random weights:
-        #   * one object, on clips whose masks HAVE a boundary (tests/live_fixture.py: foreground 20-35 % of the frame, 1-10 % of
-        #     the pixels within 0.1 of the threshold; a read-out noised by 1 % FAILS the same comparison): 'f16' 0.99993-0.99997,
-        #     foreground logits within 1.3e-3 (an IoU loss of 1e-3 corresponds to ~2e-2); 'qx' and 'split' 0.99999-1.00000, logits
-        #     within 1e-4 -- the exact-fp32 GPU loop's own distance from the CPU path (MIOpen vs CPU convolutions);
-        #   * three / five objects (20-30 frame clips): exact fp32 0.9997-1.0000, 'qx' 0.9993-0.9997, 'f16' 0.9986-0.9995: with
-        #     several objects the soft aggregation amplifies the read's error and 'f16' is not reliably inside the bar.
+        #   'qx'    = 'f16' with the QUERY as a hi/lo pair (two terms for the logits);
+        #   'auto' (default) = decided per clip, from what is MEASURED on the clip [r6]:
+        #       * clips with several objects: 'split' (the soft aggregation amplifies the read's error: on 3 / 5-object clips 'qx' is at
+        #         0.9993-0.9997 and 'f16' at 0.9986-0.9995 of the CPU path's masks -- inside the task's 1e-3 only just, or not at all);
+        #       * clips with one object: 'f16' -- and the bank keeps the largest affinity logit its reads have seen (rmnet_hip.h, logit
+        #         word); when that exceeds AUTO_LOGIT_BOUND the clip is read again in 'split', like a clip whose values left the bank's
+        #         fp16 window.  Why: rounding K and q to 11 bits costs ~2^-11 |S| per logit.  With near-uniform soft-maxes (the
+        #         procedural weights: |S| < 10) that averages out -- 'f16' is at 0.99991-0.99997 on live-boundary clips -- but with the
+        #         key convolutions scaled so that the soft-max is peaked (top-1 mass 0.5: |S| ~ 150) 'f16' AND 'qx' fall to 0.9985-0.9990,
+        #         below the bar, while 'split' stays on the exact loop (profiles/r06_iou_temperature.md; tests/test_gpu_parity.py
+        #         test_key_temperature_sweep).  No trained checkpoint is reachable offline: the bound is what the sweep supports.
         self.read_precision = ops._loop_precision(read_precision)
         self.encoder_memory = EncoderMemory()
         self.encoder_query = EncoderQuery()
@@ -311,19 +318,21 @@ class RMNet(nn.Module):
                 begin.append(begin[-1] + n)
             self.obj_begin = torch.tensor(begin, dtype=torch.int32, device=device)
 
-    def new_bank(self, ctx, capacity, exact=False):
+    def new_bank(self, ctx, capacity, exact=False, precision=None):
         """Pre-allocated regional memory for one clip (replaces models/rmnet.py:191-205, 416-426): the
         split-fp16 ``MemoryBank`` (any number of frames: beyond 2048 the read runs in chunks that are merged by their
         soft-max state), or -- ``exact`` -- plain fp32 tensors read by the exact-fp32 kernel (``TensorBank``)."""
         if exact:
             return ops.TensorBank(len(ctx.flat), capacity, ctx.h, ctx.w, ctx.device)
-        return ops.MemoryBank(len(ctx.flat), capacity, ctx.h, ctx.w, ctx.device, precision=self.resolve_read_precision(ctx.n_max))
+        return ops.MemoryBank(len(ctx.flat), capacity, ctx.h, ctx.w, ctx.device,
+                              precision=precision or self.resolve_read_precision(ctx.n_max))
 
     def resolve_read_precision(self, n_objects):
-        """The arithmetic ``read_precision`` stands for on clips with ``n_objects`` objects each ('auto': see __init__)."""
+        """The arithmetic a clip with ``n_objects`` objects per batch element STARTS in ('auto': see __init__; a one-object clip whose
+        logits turn out large is re-read in 'split' at the end of ``forward``)."""
         if self.read_precision != 'auto':
             return self.read_precision
-        return 'f16' if all(int(n) <= 1 for n in n_objects) else 'qx'
+        return 'f16' if all(int(n) <= 1 for n in n_objects) else 'split'
 
     @torch.no_grad()
     def frame_step(self, ctx, bank, prev_frame, prev_mask, cur_frame, cur_flow, commit):
@@ -353,7 +362,7 @@ class RMNet(nn.Module):
 
     @torch.no_grad()
     def forward(self, frames, masks, optical_flows, n_objects, memorize_every, device=None, _exact=False, graph=None,
-                return_logits=False):
+                return_logits=False, _precision=None):
         """models/rmnet.py:385-452.  frames [B,N,3,H,W] f32, masks [B,N,K,H,W] (one-hot, any int or
         float dtype), optical_flows [B,N,2,H,W] f32, n_objects [B,N] int -> est_masks [B,N,K,H,W]
         f32 on the GPU (the reference returns them on the host unless several GPUs are visible).
@@ -386,7 +395,7 @@ class RMNet(nn.Module):
         fresh = {j for j in range(1, N) if bool((n_obj_host[:, j] != n_obj_host[:, j - 1]).any())}
         commit = set(range(0, N, memorize_every)) | fresh
         ctx = self._ClipContext(self, B, K, H, W, n_max, dev)
-        bank = self.new_bank(ctx, sum(1 for j in commit if j <= N - 2) + 1, exact=_exact)
+        bank = self.new_bank(ctx, sum(1 for j in commit if j <= N - 2) + 1, exact=_exact, precision=_precision)
 
         # (a bank of more than one launch's frames is read in host-planned chunks: its frame count would be baked into the capture)
         use_graph = bool(graph) and isinstance(bank, ops.MemoryBank) and bank.capacity <= ops.BANK_MAX_SLOTS
@@ -422,13 +431,23 @@ class RMNet(nn.Module):
             est[:, t] = F.softmax(logit, dim=1) if prob is None else prob
             if return_logits:
                 logits[:, t] = logit
-        if bank.overflow_count():   # (one host sync per clip) K / V / q_key outside the split-fp16 window: redo the clip exactly
-            if isinstance(bank, ops.MemoryBank) and bank.timeout_count():
+        overflow, timeouts, logit_max = bank.status()      # (one host sync per clip)
+        self.last_clip = {'read_precision': getattr(bank, 'precision', 'exact'), 'logit_max': logit_max, 'reread': None}
+        if overflow:                # K / V / q_key outside the split-fp16 window: redo the clip exactly
+            if timeouts:
                 import warnings
                 warnings.warn('rmnet_amd: %d merge(s) of the bank read timed out on this device (scheduling problem?); '
-                              'the clip is re-read with the exact-fp32 kernels' % bank.timeout_count())
-            return self.forward(frames, masks, optical_flows, n_objects, memorize_every, device=dev, _exact=True,
-                                return_logits=return_logits)
+                              'the clip is re-read with the exact-fp32 kernels' % timeouts)
+            out = self.forward(frames, masks, optical_flows, n_objects, memorize_every, device=dev, _exact=True,
+                               return_logits=return_logits)
+            self.last_clip['reread'] = 'exact: value outside the bank\'s fp16 window'
+            return out
+        if self.read_precision == 'auto' and self.last_clip['read_precision'] in ('f16', 'qx') and logit_max > AUTO_LOGIT_BOUND:
+            # 'auto' on a clip whose soft-max turned out peaked: the fp16-operand read is not inside the bar there (see __init__)
+            out = self.forward(frames, masks, optical_flows, n_objects, memorize_every, device=dev, graph=graph,
+                               return_logits=return_logits, _precision='split')
+            self.last_clip['reread'] = 'split: largest logit %.1f > %.1f' % (logit_max, AUTO_LOGIT_BOUND)
+            return out
         return (est, logits) if return_logits else est
 
     def _capture_frame_step(self, ctx, bank, prev_frame, prev_mask, cur_frame, cur_flow):

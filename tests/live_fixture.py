@@ -39,6 +39,23 @@ LIVE_CLIPS = {
 }
 
 
+# Key-temperature points of the one-object fixtures (tools/iou_temperature.py, profiles/r06_iou_temperature.md): the key convolutions of both
+# KeyValue heads scaled by s (every affinity logit by s^2) and the bias shift at which the clip is live at that point (bisection on the CPU path).
+TEMPERATURE_POINTS = {
+    'live480-a': {1.0: -5.5, 2.0: -5.5, 4.0: -8.0, 8.0: -8.0},
+    'live240': {1.0: -5.23, 2.0: -7.23, 4.0: -8.73, 8.0: -8.73},
+}
+
+
+@torch.no_grad()
+def scale_keys(net, s):
+    """Both KeyValue heads' key convolutions x s (weight and bias): k -> s k, q -> s q, every affinity logit (models/rmnet.py:155-157) -> s^2 x."""
+    for kv in (net.kv_memory, net.kv_query):
+        kv.key_conv.weight.mul_(s)
+        kv.key_conv.bias.mul_(s)
+    return net
+
+
 def make_clip(name, N=None, every=None):
     """-> (frames, masks, flows, n_objects, memorize_every, delta) of fixture ``name`` (optionally longer / another cadence)."""
     from rmnet_amd.synthetic import synthetic_clip

@@ -11,7 +11,9 @@
 //      last arriver merges from) names exactly their slots;
 //   4. a chunk never starts more segments than the merge scratch allows, no chunk is longer than C tile units;
 //   5. the plan's search for C ends with no more chunks than workgroups, with and without "own column blocks", and with the
-//      EQUALISED blocks (no remainder chunks; block lengths differ by at most one tile and never exceed C).
+//      EQUALISED blocks (no remainder chunks; block lengths differ by at most one tile and never exceed C);
+//   6. [r6] a launch with more pairs than workgroups runs in ROUNDS: whole objects first (one column block each), the objects behind them cut
+//      into equal blocks that fill one more round; no remainder chunks, slots only for the cut objects, at most R + 2 rounds.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -130,6 +132,38 @@ void check_launch(const std::vector<int>& nqt, const std::vector<int>& njt, int 
   int njt_max = 0;
   for (size_t o = 0; o < nqt.size(); ++o) { W += (long long)nqt[o] * njt[o]; njt_max = std::max(njt_max, njt[o]); }
   auto total = [&](int C, int own) { int n = 0; for (size_t o = 0; o < nqt.size(); ++o) n += bank_chunks(nqt[o], njt[o], C, sc, own).nch; return n; };
+  // [r6] more pairs than workgroups: ROUNDS of aligned chunks (common.h: bank_round_chunk_len; bank.hip, the plan)
+  {
+    int P = 0, nq_max = 0;
+    for (size_t o = 0; o < nqt.size(); ++o) { P += njt[o] > 0 ? nqt[o] : 0; nq_max = std::max(nq_max, nqt[o]); }
+    if (P > target) {
+      const int R = P / target;
+      int Pw = 0, ps = 0;
+      for (size_t o = 0; o < nqt.size(); ++o) { ps += njt[o] > 0 ? nqt[o] : 0; if (ps <= R * target) Pw = std::max(Pw, ps); }
+      long long N = 0, slots = 0;
+      bool split_seen = false;
+      ps = 0;
+      for (size_t o = 0; o < nqt.size(); ++o) {
+        ps += njt[o] > 0 ? nqt[o] : 0;
+        const int Co = bank_round_chunk_len(njt[o], ps, P, Pw, target, cq);
+        const BankChunks bc = bank_chunks(nqt[o], njt[o], Co, sc, 2);
+        CHECK(bc.R == 0 && bc.nrem == 0, "rounds: object %zu has remainder chunks", o);
+        if (njt[o] > 0 && nqt[o] > 0) {
+          if (ps <= R * target) {
+            CHECK(bc.nfull == 1 && !split_seen, "rounds: object %zu inside the whole rounds is cut in %d blocks (or follows a split object)", o, bc.nfull);
+          } else {
+            split_seen = true;
+          }
+        }
+        N += bc.nch;
+        slots += bc.nfull > 1 ? bc.nch : 0;
+        check_object(nqt[o], njt[o], Co, sc, 2);
+      }
+      CHECK(N <= (long long)(R + 2) * target + nq_max, "rounds: %lld chunks on %d workgroups are more than %d rounds (P %d)", N, target, R + 2, P);
+      CHECK(slots <= (long long)kSplitTargetSlots + (long long)nqt.size() * nq_max, "rounds: %lld partial slots exceed the workspace of a launch group", slots);
+      return;
+    }
+  }
   int C0 = std::max((int)((W + target - 1) / target), bank_chunk_min(njt_max));
   C0 = (C0 + cq - 1) / cq * cq;
   int it = 0;

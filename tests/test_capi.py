@@ -32,7 +32,7 @@ def test_library_builds_and_exports_every_header_symbol():
 def test_error_strings_and_sizes_need_no_gpu():
     from rmnet_amd import _lib
     lib = _lib.load()
-    assert lib.rmnet_abi_version() == 5
+    assert lib.rmnet_abi_version() == 6
     assert lib.rmnet_error_string(0) == b'ok'
     for code in (-1, -2, -3, -4):
         assert len(lib.rmnet_error_string(code)) > 4
@@ -85,7 +85,7 @@ def test_flag_constants_of_the_python_mirror_match_the_header():
     from rmnet_amd.rmnet import MemoryReader, RMNet
     src = open(os.path.join(ROOT, 'include', 'rmnet_hip.h')).read()
     defs = {m.group(1): int(m.group(2)) for m in re.finditer(r'^#define\s+(RMNET_\w+)\s+(-?\d+)\b', src, re.M)}
-    assert defs['RMNET_ABI_VERSION'] == _lib.ABI_VERSION == 5
+    assert defs['RMNET_ABI_VERSION'] == _lib.ABI_VERSION == 6
     assert defs['RMNET_MR_FORCE_GENERIC'] == ops.MR_FORCE_GENERIC and defs['RMNET_MR_EXACT_FP32'] == ops.MR_EXACT_FP32
     assert defs['RMNET_MR_F16'] == ops.MR_F16 == defs['RMNET_BANK_F16'] == ops.BANK_F16
     assert len({defs['RMNET_MR_FORCE_GENERIC'], defs['RMNET_MR_EXACT_FP32'], defs['RMNET_MR_F16']}) == 3   # distinct bits
@@ -96,7 +96,7 @@ def test_flag_constants_of_the_python_mirror_match_the_header():
         RMNet(None, read_precision='fp8')
     net = RMNet(None)
     assert net.read_precision == 'auto' and MemoryReader().precision == 'split'      # the stand-alone reader: fp32-class unless asked
-    assert net.resolve_read_precision([1, 1, 1]) == 'f16' and net.resolve_read_precision([1, 3]) == 'qx'   # calibrated per-clip choice (profiles/r05_iou_calibration.md)
+    assert net.resolve_read_precision([1, 1, 1]) == 'f16' and net.resolve_read_precision([1, 3]) == 'split'   # per-clip choice (profiles/r05_iou_calibration.md, r06_iou_temperature.md)
     assert RMNet(None, read_precision='f16').resolve_read_precision([5]) == 'f16'
     lib = _lib.load()
     assert defs['RMNET_MR_QX'] == ops.MR_QX == defs['RMNET_BANK_QX'] == ops.BANK_QX

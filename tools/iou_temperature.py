@@ -1,0 +1,179 @@
+# -*- coding: utf-8 -*-
+"""Key-temperature sweep of the bank read's arithmetic modes (round-5 verdict, "next" item 3).  TEST INFRASTRUCTURE.
+
+No trained checkpoint is reachable offline, and the procedural random weights give affinity logits of O(1): a near-uniform soft-max,
+the regime where fp16 rounding of K / q / P / V averages out.  A trained network's soft-max is peaked.  This tool makes the SAME
+network peaked: the key convolutions of both KeyValue heads (models/rmnet.py:172, `key_conv` of kv_memory and kv_query) are scaled by
+s in {1, 2, 4, 8}, i.e. every logit S_ij = k_j . q_i / sqrt(128) (models/rmnet.py:155-157) by s^2 -- from near-uniform to a top-1 mass
+above 0.5 -- and prices each arithmetic at each point:
+
+    CPU  (default)   the CPU path (oracle.OracleRMNet) against itself with MemoryReader.forward replaced by
+                     tests/live_fixture.rounded_reader (K / q / P / V rounded the way csrc/bank.hip's modes round them)
+    GPU  (--gpu)     the HIP loop (rmnet_amd.RMNet) in exact / split / qx / f16 against the CPU path
+
+One-object clips are the live-boundary fixtures of tests/live_fixture.py with the decoder's foreground bias re-chosen PER POINT (the
+read-out changes with s, so the 0.5 level set moves): a bisection on the CPU path towards a foreground cover of ~0.3 on the last frame,
+accepted when every frame passes live_fixture.assert_live's window.  Multi-object clips need no shift (the objects compete in the soft
+aggregation: their boundaries are live as they are).
+
+    python tools/iou_temperature.py [--gpu] [--fixtures live480-a,3obj-480p] [--scales 1,2,4,8] [--out profiles/x.md]
+"""
+import argparse, json, math, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import torch
+from oracle import oracle
+from rmnet_amd import networks
+from rmnet_amd.synthetic import synthetic_clip
+import live_fixture as lf
+
+torch.set_grad_enabled(False)
+
+MULTI = {   # name -> (n_obj, H, W, memorize_every, seed, blob size, frames)
+    '3obj-480p': (3, 480, 854, 2, 3, 1.6, 8),
+    '3obj-240p': (3, 240, 432, 2, 3, 1.6, 6),
+}
+
+
+@torch.no_grad()
+def scale_keys(net, s):
+    """Both KeyValue heads' key convolutions x s (weight and bias): k -> s k, q -> s q, every affinity logit -> s^2 x."""
+    for kv in (net.kv_memory, net.kv_query):
+        kv.key_conv.weight.mul_(s)
+        kv.key_conv.bias.mul_(s)
+    return net
+
+
+def cpu_net(reader, s, delta):
+    net = networks.procedural_init_(oracle.OracleRMNet(reader=reader)).eval()
+    return lf.shift_foreground_bias(scale_keys(net, s), delta)
+
+
+class StatReader:
+    """torch MemoryReader.forward (models/rmnet.py:147-165) that also records the soft-max's shape at every call."""
+
+    def __init__(self):
+        self.rows = []
+
+    def __call__(self, m_key, m_val, q_key, q_val):
+        no, De, T, h, w = m_key.shape
+        K = m_key.reshape(no, De, -1)
+        q = q_key.reshape(no, De, -1)
+        S = torch.bmm(K.transpose(1, 2), q) / math.sqrt(De)          # [no, THW, hw]
+        P = torch.softmax(S, dim=1)
+        mem = torch.bmm(m_val.reshape(no, -1, T * h * w), P).reshape(no, -1, h, w)
+        live = q.abs().sum(dim=1) > 0                                 # query cells inside the box
+        top1 = P.max(dim=1).values
+        ent = -(P * torch.log(P.clamp_min(1e-30))).sum(dim=1)
+        if bool(live.any()):
+            self.rows.append((float(S.abs().max()), float(top1[live].mean()), float(top1[live].max()), float(ent[live].mean()), math.log(T * h * w)))
+        return torch.cat([mem, q_val], dim=1), None
+
+
+def clip_of(name):
+    if name in MULTI:
+        n_obj, H, W, every, seed, size, N = MULTI[name]
+        frames, masks, flows, n_objects = synthetic_clip(N, n_obj + 1, H, W, seed=seed, size=size)
+        return frames, masks, flows, n_objects, every, None, n_obj
+    frames, masks, flows, n_objects, every, delta = lf.make_clip(name)
+    return frames, masks, flows, n_objects, every, delta, 1
+
+
+def is_live(est):
+    try:
+        lf.assert_live(est)
+        return True
+    except AssertionError:
+        return False
+
+
+def choose_delta(clip, s, start):
+    """Bias shift at which the one-object clip is live with the keys scaled by s (bisection on the last frame's cover)."""
+    frames, masks, flows, n_objects, every = clip
+    lo, hi = start - 4.0, start + 4.0                                 # cover grows with delta
+    best = None
+    d = start
+    for it in range(9):
+        est = cpu_net('torch', s, d)(frames, masks, flows, n_objects, every)
+        cov = [c for c, _ in lf.liveness(est)]
+        ok = is_live(est)
+        print('    scan s=%g delta %.3f: cover %s %s' % (s, d, ' '.join('%.2f' % c for c in cov), 'LIVE' if ok else ''), flush=True)
+        if ok:
+            best = d
+            if 0.2 <= cov[-1] <= 0.45:
+                return d
+        if max(cov) > 0.6 or cov[-1] > 0.45:
+            hi = d
+        else:
+            lo = d
+        d = 0.5 * (lo + hi)
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpu', action='store_true')
+    ap.add_argument('--fixtures', default='live480-a,3obj-480p')
+    ap.add_argument('--scales', default='1,2,4,8')
+    ap.add_argument('--threads', type=int, default=8)
+    ap.add_argument('--out', default='')
+    ap.add_argument('--deltas', default='', help='JSON {fixture: {scale: delta}} from an earlier run: skip the bisection')
+    args = ap.parse_args()
+    torch.set_num_threads(args.threads)
+    known = json.loads(args.deltas) if args.deltas else {}
+    lines = []
+
+    def emit(sx):
+        print(sx, flush=True)
+        lines.append(sx)
+
+    emit('| clip | key scale s (logits x s^2) | bias shift | max abs logit | top-1 mass: mean / max over the query cells | soft-max entropy / ln(THW) | arithmetic | clip IoU (min over objects) | largest live fg-logit gap |')
+    emit('|---|---|---|---|---|---|---|---|---|')
+    chosen = {}
+    for name in args.fixtures.split(','):
+        frames, masks, flows, n_objects, every, delta0, n_obj = clip_of(name)
+        for s in [float(x) for x in args.scales.split(',')]:
+            t0 = time.time()
+            delta = 0.0
+            if delta0 is not None:
+                kd = known.get(name, {}).get('%g' % s)
+                delta = kd if kd is not None else (delta0 if s == 1.0 else choose_delta((frames, masks, flows, n_objects, every), s, delta0))
+                if delta is None:
+                    emit('| %s | %g | no live shift found | | | | | | |' % (name, s))
+                    continue
+            chosen.setdefault(name, {})['%g' % s] = delta
+            stat = StatReader()
+            ref, ref_l = cpu_net(stat, s, delta)(frames, masks, flows, n_objects, every, return_logits=True)
+            smax = max(r[0] for r in stat.rows)
+            t1 = sum(r[1] for r in stat.rows) / len(stat.rows)
+            t1m = max(r[2] for r in stat.rows)
+            ent = sum(r[3] / r[4] for r in stat.rows) / len(stat.rows)
+            live = is_live(ref) if n_obj == 1 else True
+            head = '| %s | %g | %s | %.1f | %.3f / %.3f | %.3f |' % (name, s, ('%.3f%s' % (delta, '' if live else ' (NOT live)')) if delta0 is not None else 'none', smax, t1, t1m, ent)
+            if args.gpu:
+                from rmnet_amd.rmnet import RMNet
+                dev = torch.device('cuda', 0)
+                for mode in ('exact', 'split', 'qx', 'f16', 'auto'):
+                    net = networks.procedural_init_(RMNet(None, read_precision='split' if mode == 'exact' else mode)).eval()
+                    lf.shift_foreground_bias(scale_keys(net, s), delta)
+                    net = net.to(dev).fuse_epilogues()
+                    est, lg = net(frames, masks, flows, n_objects, every, device=dev, return_logits=True, _exact=(mode == 'exact'))
+                    est, lg = est.cpu(), lg.cpu()
+                    ious = [lf.label_iou(est, ref, k) for k in range(1, n_obj + 1)]
+                    emit('%s GPU %s | %.5f | %.2e |' % (head, mode, min(ious), lf.logit_gap(lg, ref_l)))
+            else:
+                for mode in ('f16', 'qx', 'mixed'):
+                    est, lg = cpu_net(lf.rounded_reader(mode), s, delta)(frames, masks, flows, n_objects, every, return_logits=True)
+                    ious = [lf.label_iou(est, ref, k) for k in range(1, n_obj + 1)]
+                    emit('%s emulated %s | %.5f | %.2e |' % (head, mode, min(ious), lf.logit_gap(lg, ref_l)))
+            print('   (%s s=%g: %.0f s)' % (name, s, time.time() - t0), flush=True)
+    emit('')
+    emit('bias shifts used: `%s`' % json.dumps(chosen))
+    if args.out:
+        with open(args.out, 'w') as f:
+            f.write('\n'.join(lines) + '\n')
+
+
+if __name__ == '__main__':
+    main()
