@@ -728,6 +728,37 @@ def main():
             step1(i)
         torch.cuda.synchronize()
         extras['single_stream_fps'] = round(20 / (time.perf_counter() - t1), 2)
+        # ... and what a single-stream frame is made of: GPU-busy time (sum of the kernels' device time) against wall time per frame.
+        # busy ~ wall: bound by the batch-1 kernels themselves (a HIP graph cannot help); busy << wall: launch gaps
+        try:
+            if os.environ.get('BENCH_NO_PROFILER') == '1':
+                raise RuntimeError('skipped (BENCH_NO_PROFILER=1)')
+            from torch.profiler import ProfilerActivity, profile
+            with profile(activities=[ProfilerActivity.CUDA]) as prof1:
+                for i in range(4):
+                    step1(i)
+                torch.cuda.synchronize()
+            own1 = conv1 = tot1 = 0.0
+            nk = 0
+            for evt in prof1.key_averages():
+                dt_us = float(getattr(evt, 'device_time_total', 0.0) or getattr(evt, 'cuda_time_total', 0.0))
+                if dt_us <= 0.0:
+                    continue
+                tot1 += dt_us
+                nk += int(getattr(evt, 'count', 0))
+                if 'rmnet' in evt.key:
+                    own1 += dt_us
+                elif any(k in evt.key.lower() for k in ('conv', 'winograd', 'gemm', 'igemm', 'miopen', 'cijk', 'sp3asm', 'naive_conv')):
+                    conv1 += dt_us
+            wall_ms = 1e3 / extras['single_stream_fps']
+            extras['single_stream'] = {
+                'fps': extras['single_stream_fps'], 'wall_ms_per_frame': round(wall_ms, 3), 'gpu_busy_ms_per_frame': round(tot1 / 4e3, 3),
+                'busy_over_wall': round(tot1 / 4e3 / wall_ms, 3), 'kernel_launches_per_frame': round(nk / 4.0, 1),
+                'convolution_gemm_share_of_busy': round(conv1 / max(tot1, 1e-9), 4), 'hand_written_share_of_busy': round(own1 / max(tot1, 1e-9), 4),
+                'note': 'the reference\'s operating point (core/inference.py:22-28: one clip at a time): torch.profiler device records of 4 frames; '
+                        'busy_over_wall near 1 = the batch-1 kernels themselves fill the frame, not launch gaps'}
+        except Exception as exc:
+            extras['single_stream'] = {'error': repr(exc)[:200]}
         # ---- the same single stream with the step (TinyFlowNet + frame_step) captured ONCE as a HIP graph and replayed
         #      (SURVEY 8f-3): ~340 launches per frame become one graph launch + three input copies
         try:
@@ -842,9 +873,9 @@ def main():
                              'loop\'s default for clips with one object -- on one-object 480x854 clips whose masks HAVE a boundary (tests/live_fixture.py) '
                              'mask IoU vs the CPU path 0.99993-0.99997 and foreground logits within 1.3e-3 (an IoU loss of 1e-3 ~ 2e-2); the same comparison '
                              'FAILS (0.9969) when the read-out is noised by 1 % (profiles/r05_iou_calibration.md, tests/test_gpu_parity.py).  [r6] \'auto\' keeps '
-                             'it only while the largest affinity logit the bank has MEASURED on the clip stays below %.0f (this run: %.1f): with the key '
-                             'convolutions scaled until the soft-max is peaked (top-1 mass 0.5, logits ~150) f16 and qx fall to 0.9985-0.9990 and '
-                             'the clip is re-read in split (profiles/r06_iou_temperature.md)' % (AUTO_BOUND, logit_max)}[args.read_precision],
+                             'it only while the largest affinity logit the bank has MEASURED on the clip stays below ' + ('%.0f (this run: %.1f)' % (AUTO_BOUND, logit_max)) +
+                             ': with the key convolutions scaled until the soft-max is peaked (top-1 mass 0.5, logits ~150) f16 and qx fall to 0.9985-0.9990 and '
+                             'the clip is re-read in split (profiles/r06_iou_temperature.md)'}[args.read_precision],
             'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: 480x854 synthetic clips, 1 object each (K=2), memory pinned '
                                    'at T=5, TinyFlowNet + memorize + regional read + decoder per frame; '

@@ -1367,7 +1367,9 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   // object of chunk c = the last one whose chunk base is <= c (objects without chunks share the next one's base: the later one
   // wins); lane i looks at object i, and the nine plan values of the object travel LDS -> registers -> SGPRs in ONE round trip
   // (a serial search + a dozen dependent LDS reads cost ~1 us here)
-  const int li = tid & 63;
+  int li = tid & 63;
+  asm volatile("" : "+v"(li));   // opaque per chunk: inside the rounds loop hipcc hoists the ten per-lane LDS addresses below out of the
+                                 // loop and SPILLS them -- ten scratch round trips in front of every chunk's walk (r6: +5 us in the loop)
   const bool lv = li < ng;
   const int v_cb = lv ? o_cb[li] : 0x7fffffff, v_nqt = lv ? o_nqt[li] : 0, v_njt = lv ? o_njt[li] : 0, v_sb = lv ? o_sb[li] : 0;
   const int v_m = lv ? o_m[li] : 0, v_r0 = lv ? o_rect[li][0] : 0, v_r1 = lv ? o_rect[li][1] : 0, v_r2 = lv ? o_rect[li][2] : 0;

@@ -8,6 +8,8 @@
 #   tests [-k e]   pytest -m gpu (optionally a -k expression)
 #   bench [args]   python bench.py [args]
 #   prof  [args]   rocprofv3 --kernel-trace --stats of bench.py [args] -> kernel table (tools/rocprof_summary.py)
+#   conv_layout    the convolution half of 8f-3: fused / unfused / folded / channels_last frames/s + the NHWC run's kernel table
+#   record         the round's record: suite + smoke, default bench line, rocprofv3 table, PMC traffic x 3, in-loop counters, stress
 #   cmd   <...>    any command line
 set -u
 cd "$(dirname "$0")/.."
@@ -49,8 +51,39 @@ prof)
   cd /tmp
   rocprofv3 --kernel-trace --stats -d $OLDPWD/$out/prof -o run -- python $OLDPWD/bench.py "$@" > $OLDPWD/$out/bench_under_rocprof.json 2> $OLDPWD/$out/prof.err
   cd $OLDPWD
-  python tools/rocprof_summary.py $out/prof > $out/kernel_table.md 2>> $out/log.txt || true
-  find $out/prof -name "*kernel_trace.csv" -size +8M -delete
+  db=$(find $out/prof -name "*.db" | head -1)
+  python tools/rocprof_summary.py $db 45 --steady 20 > $out/kernel_table.md 2>> $out/log.txt || true
+  find $out/prof -type f -size +4M -delete
+  ;;
+conv_layout)
+  # the convolution half of SURVEY 8f-3: frames/s of the bench loop with the elementwise glue fused (default, NCHW), unfused, with the
+  # BatchNorms folded into the convolutions, and channels_last (unfused; MIOpen asked for NHWC); rocprofv3 kernel table of the last
+  for v in "fused_nchw" "unfused_nchw --no-fuse-epilogue" "foldbn_nchw --fold-bn" "unfused_nhwc --channels-last"; do
+    set -- $v; name=$1; shift
+    log "$name: bench.py --no-extras --no-cpu-baseline $*"
+    PYTORCH_MIOPEN_SUGGEST_NHWC=$([ "$name" = unfused_nhwc ] && echo 1 || echo 0) timeout 900 python bench.py --no-extras --no-cpu-baseline "$@" > $out/$name.json 2> $out/$name.err
+    python tools/show_line.py $out/$name.json 2>&1 | head -1 | tee -a $out/log.txt
+  done
+  cd /tmp
+  PYTORCH_MIOPEN_SUGGEST_NHWC=1 rocprofv3 --kernel-trace --stats -d $OLDPWD/$out/prof_nhwc -o run -- python $OLDPWD/bench.py --no-extras --no-cpu-baseline --channels-last > $OLDPWD/$out/nhwc_under_rocprof.json 2> $OLDPWD/$out/prof.err
+  cd $OLDPWD
+  db=$(find $out/prof_nhwc -name "*.db" | head -1)
+  python tools/rocprof_summary.py $db 45 --steady 20 > $out/kernel_table_nhwc.md 2>> $out/log.txt || true
+  find $out/prof_nhwc -type f -size +4M -delete
+  ;;
+record)
+  # a round's record on one box: GPU suite + smoke, the default bench line, its rocprofv3 kernel table (same command), PMC traffic of the
+  # three arithmetics (stamped with bench.source_hash()), SQ / TCC counters of bk_main inside the loop, stress.  Evidence -> profiles/ by hand.
+  run timeout 1500 python -m pytest tests -q -m gpu --durations=15
+  run python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"
+  log "python bench.py"
+  timeout 1200 python bench.py > $out/bench_line.json 2> $out/bench.err; python tools/show_line.py $out/bench_line.json | tee -a $out/log.txt
+  bash tools/profile_round.sh > $out/profile_round.txt 2>&1; cp gpurun_out/prof/timed_region.md $out/timed_region.md; cp gpurun_out/prof/bench_line.json $out/bench_line_under_rocprof.json
+  for prec in f16 qx split; do PRECISION=$prec bash tools/pmc_traffic.sh > $out/pmc_traffic_$prec.txt 2>&1; done
+  cp profiles/bk_main*_hbm_traffic.json $out/
+  mkdir -p build/variants; cp rmnet_amd/librmnet_hip.so build/variants/lib_main.so
+  VARIANTS="main" bash tools/pmc_loop.sh $tag/counters > /dev/null 2>&1; cp gpurun_out/$tag/counters/summary.txt $out/counters.txt
+  for mode in f16 qx split; do RMNET_BANK_PRECISION=$mode timeout 900 python tests/stress_race.py 150 2>&1 | tail -1; done | tee $out/stress.txt
   ;;
 cmd)
   run "$@"
