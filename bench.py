@@ -390,7 +390,12 @@ def main():
                          '(default: one rmnet_channel_affine_f32 pass per convolution)')
     ap.add_argument('--fold-bn', action='store_true',
                     help='fold eval-mode BatchNorm into the trunk convolutions (measured: no gain at 4 clips/GPU)')
-    ap.add_argument('--channels-last', action='store_true', help='conv stacks in NHWC memory format (experiment)')
+    ap.add_argument('--nchw', dest='channels_last', action='store_false',
+                    help='keep both networks in NCHW memory format (the layout of rounds 1-5).  Default since round 6: channels_last -- MIOpen NHWC '
+                         'kernels without the layout transposes that wrap them on NCHW tensors, channels-last glue kernels: +7 %% frames/s '
+                         '(profiles/r06_conv_layout.md)')
+    ap.add_argument('--channels-last', dest='channels_last', action='store_true', help='(the default; kept for scripts that pass it)')
+    ap.set_defaults(channels_last=True)
     ap.add_argument('--clips-per-gpu', type=int, default=DEFAULT_CLIPS,
                     help='independent clips batched on every GPU (one 480p clip cannot fill 256 CUs; measured on MI355X in round 5, '
                          'profiles/r05_c_plan_and_tail_experiments.md: 164 / 227 / 253.7 / 261.2 / 260.6 / 267.4 frames/s at 1 / 4 / 8 / 12 / 16 / 32 clips). '
@@ -405,6 +410,8 @@ def main():
     ap.add_argument('--dist-backend', default=None, help="override the process-group backend ('gloo' lets several "
                     "ranks share one GPU when testing the N>1 path on a 1-GPU box)")
     args = ap.parse_args()
+    if args.channels_last:          # (read by ATen when the first convolution runs: channels_last tensors then go to MIOpen as NHWC)
+        os.environ.setdefault('PYTORCH_MIOPEN_SUGGEST_NHWC', '1')
 
     from rmnet_amd import dist as rd
     from rmnet_amd import networks
@@ -437,10 +444,10 @@ def main():
     tfn = networks.procedural_init_(TinyFlowNet(None)).to(dev).eval()
     if args.fold_bn:
         net.fuse_for_inference()
-    elif not args.no_fuse_epilogue and not args.channels_last:
+    elif not args.no_fuse_epilogue:
         net.fuse_epilogues()
         tfn.fuse_epilogues()
-    if args.channels_last:
+    if args.channels_last:          # [r6] the fused glue kernels have channels-last variants (csrc/epilogue.hip): the layout no longer costs the fusion
         net = net.to(memory_format=torch.channels_last)
         tfn = tfn.to(memory_format=torch.channels_last)
     n_clip = 12
@@ -561,7 +568,8 @@ def main():
     # the OTHER arithmetic mode of the same kernel on the same launches (same bank, same boxes), outside the timed region
     other_modes = [m for m in ('split', 'qx', 'f16') if m != args.read_precision]
     other_ms = None
-    if not args.no_extras and not args.extras_child:
+    small_ms = {}
+    if not args.no_extras and not args.extras_child and world == 1:     # (secondary figures: the one-GPU line only)
         other_ms = {}
         for om in other_modes:
             bank.precision = om
@@ -578,7 +586,6 @@ def main():
         # algorithms, only on what they leave in the caches).  1 = the reference's operating point (core/inference.py:22-28: one clip
         # at a time); <= 8: every (object, query tile) pair is cut into column blocks and merged by its last arriver; 16: one workgroup
         # per pair; > 19: more pairs than workgroups -- the launch runs in ROUNDS (csrc/common.h: bank_round_chunk_len).
-        small_ms = {}
         find = torch.backends.cudnn.benchmark
         torch.backends.cudnn.benchmark = False
         k_small = min(args.steps, 10)
@@ -655,7 +662,7 @@ def main():
         cmd = [sys.executable, os.path.abspath(__file__), '--extras-child', '--steps', '3', '--warmup', '2', '--no-cpu-baseline',
                '--clips-per-gpu', str(args.clips_per_gpu), '--read-precision', requested_precision]
         for flag, on in (('--no-miopen-find', args.no_miopen_find), ('--no-fuse-epilogue', args.no_fuse_epilogue), ('--fold-bn', args.fold_bn),
-                         ('--channels-last', args.channels_last)):
+                         ('--nchw', not args.channels_last)):
             if on:
                 cmd.append(flag)
         _phase('extras: child process')
@@ -887,7 +894,7 @@ def main():
                        'miopen_find': not args.no_miopen_find, 'channels_last': bool(args.channels_last),
                        'hip_graph': bool(args.graph), 'clips_per_gpu': B,
                        'batchnorm_folded': bool(args.fold_bn),
-                       'fused_epilogues': bool(not args.fold_bn and not args.no_fuse_epilogue and not args.channels_last)},
+                       'fused_epilogues': bool(not args.fold_bn and not args.no_fuse_epilogue)},
             'roofline': {'bound': 'mfma',
                          'kernel': 'bk_main<%d> = the whole regional memory read in ONE launch (%s MFMA read of the bank, merge of the '
                                    'partial results by the last workgroup of every query tile, masked cells, q_val half of the cat)'

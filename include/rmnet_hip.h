@@ -30,7 +30,7 @@ extern "C" {
                                * the read counts out-of-window query elements; sticky error bits + time-out word behind the overflow word.
                                * 5: RMNET_MR_QX / RMNET_BANK_QX (fp16 operands with an exact query); a pair whose merge timed out is
                                * written as NaN; the overflow word is a zero / non-zero flag, not an element count.
-                               * 6: the bank keeps the largest affinity logit its reads have seen (third int32 of the control block) */
+                               * 6: the bank keeps the largest affinity logit its reads have seen (third int32 of the control block); channels-last glue entries */
 
 enum {
   RMNET_OK = 0,
@@ -256,6 +256,18 @@ int rmnet_affine_relu_maxpool_f32(const float *x, const float *scale, const floa
  * (models/rmnet.py:117-119). */
 int rmnet_upsample2x_add_f32(const float *x, const float *skip, long long N, int C, int h, int w,
                              float *out, void *stream);
+
+/* C1 glue, CHANNELS-LAST variants (ABI v6): the same three passes for activations that are [N, H, W, C] in memory -- what MIOpen's NHWC
+ * convolution kernels produce and consume without layout transposes (torch: tensor.to(memory_format=torch.channels_last)).  Same arithmetic and
+ * rounding as the NCHW entries above; C % 4 == 0, every pointer 16-byte aligned (RMNET_E_INVALID_ARG otherwise).
+ *   rmnet_channel_affine_nhwc_f32:      x / res / out [rows = N*H*W][C]
+ *   rmnet_upsample2x_add_nhwc_f32:      x [N,h,w,C] -> out / skip [N,2h,2w,C]
+ *   rmnet_affine_relu_maxpool_nhwc_f32: x [N,H,W,C] -> out [N,(H-1)/2+1,(W-1)/2+1,C] */
+int rmnet_channel_affine_nhwc_f32(const float *x, const float *scale, const float *shift, const float *res, const float *res_scale,
+                                  const float *res_shift, int relu, long long rows, int C, float *out, void *stream);
+int rmnet_upsample2x_add_nhwc_f32(const float *x, const float *skip, long long N, int C, int h, int w, float *out, void *stream);
+int rmnet_affine_relu_maxpool_nhwc_f32(const float *x, const float *scale, const float *shift, long long N, int C, int H, int W,
+                                       float *out, void *stream);
 
 /* P3/P4 tail: decoder logits -> foreground probability -> soft aggregation -> un-pad (-> soft-max over
  * the K mask channels) in one pass.  dec [n_tot,2,Hp,Wp]: 2-class logits of the objects in flight;

@@ -74,6 +74,12 @@ SIGNATURES = {
     'rmnet_affine_relu_maxpool_f32': (ctypes.c_int, [
         c_f32p, c_f32p, c_f32p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p,
         ctypes.c_void_p]),
+    'rmnet_channel_affine_nhwc_f32': (ctypes.c_int, [
+        c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_longlong, ctypes.c_int, c_f32p, ctypes.c_void_p]),
+    'rmnet_upsample2x_add_nhwc_f32': (ctypes.c_int, [
+        c_f32p, c_f32p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_void_p]),
+    'rmnet_affine_relu_maxpool_nhwc_f32': (ctypes.c_int, [
+        c_f32p, c_f32p, c_f32p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_void_p]),
     'rmnet_flow_affine_f32': (ctypes.c_int, [
         c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_void_p]),
     'rmnet_flow_affine_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),

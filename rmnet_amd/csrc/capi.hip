@@ -186,6 +186,20 @@ int rmnet_affine_relu_maxpool_f32(const float* x, const float* scale, const floa
   return launch_affine_relu_maxpool(x, scale, shift, N, C, H, W, out, static_cast<hipStream_t>(stream));
 }
 
+int rmnet_channel_affine_nhwc_f32(const float* x, const float* scale, const float* shift, const float* res, const float* res_scale,
+                                  const float* res_shift, int relu, long long rows, int C, float* out, void* stream) {
+  return launch_channel_affine_nhwc(x, scale, shift, res, res_scale, res_shift, relu, rows, C, out, static_cast<hipStream_t>(stream));
+}
+
+int rmnet_upsample2x_add_nhwc_f32(const float* x, const float* skip, long long N, int C, int h, int w, float* out, void* stream) {
+  return launch_upsample2x_add_nhwc(x, skip, N, C, h, w, out, static_cast<hipStream_t>(stream));
+}
+
+int rmnet_affine_relu_maxpool_nhwc_f32(const float* x, const float* scale, const float* shift, long long N, int C, int H, int W, float* out,
+                                       void* stream) {
+  return launch_affine_relu_maxpool_nhwc(x, scale, shift, N, C, H, W, out, static_cast<hipStream_t>(stream));
+}
+
 int rmnet_flow_affine_f32(const float* flow, const float* m1, const float* m2, int H, int W,
                           float* out, void* stream) {
   return launch_flow_affine(flow, m1, m2, H, W, out, static_cast<hipStream_t>(stream));

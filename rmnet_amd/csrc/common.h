@@ -123,6 +123,12 @@ int launch_affine_relu_maxpool(const float* x, const float* scale, const float* 
                                int C, int H, int W, float* out, hipStream_t st);
 int launch_flow_affine(const float* flow, const float* m1, const float* m2, int H, int W,
                        float* out, hipStream_t st);
+// channels-last ([N, H, W, C] in memory) variants of the three glue passes (epilogue.hip)
+int launch_channel_affine_nhwc(const float* x, const float* scale, const float* shift, const float* res, const float* rscale,
+                               const float* rshift, int relu, long long rows, int C, float* out, hipStream_t st);
+int launch_upsample2x_add_nhwc(const float* x, const float* skip, long long N, int C, int h, int w, float* out, hipStream_t st);
+int launch_affine_relu_maxpool_nhwc(const float* x, const float* scale, const float* shift, long long N, int C, int H, int W, float* out,
+                                    hipStream_t st);
 
 // Split partials in the workspace: per (object, slot) a [32 channel tiles][4 query tiles][64 lanes][4]
 // fp32 block = the 16x16 MFMA accumulator fragments exactly as they sit in registers

@@ -270,7 +270,174 @@ __global__ __launch_bounds__(kThreads) void affine_relu_maxpool(const float* __r
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// [r6] The same three passes for CHANNELS-LAST activations ([N, H, W, C] in memory: what MIOpen's NHWC implicit-GEMM and CK
+// convolutions produce and consume without the batched_transpose kernels that wrap them on NCHW tensors -- 5.6 % of a step, and the
+// Winograd / rocBLAS kernels of the NCHW path are no faster than their NHWC counterparts; profiles/r06_conv_layout.md).  The channel is
+// the innermost index: a thread owns 4 consecutive channels of a pixel (C % 4 == 0 for every layer of both networks), scale / shift
+// come as float4 from the L1, rows are streamed with 16-byte accesses, 4 in flight per lane.  Same arithmetic, same rounding.
+template <bool RES, bool FIXED>
+__global__ __launch_bounds__(kThreads) void channel_affine_nhwc(const float* x, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const float* res,
+                                                                const float* __restrict__ rscale, const float* __restrict__ rshift,
+                                                                int relu, int C4, long long n4, float* out) {
+  const float lo = relu == 1 ? 0.0f : -INFINITY;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const float4* r4 = reinterpret_cast<const float4*>(res);
+  float4* o4 = reinterpret_cast<float4*>(out);
+  const float4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+  auto f = [&](float v, float sc, float sh, float r, float rs, float rh) {
+    float y = v * sc + sh;
+    if (RES) y = y + (r * rs + rh);
+    if (relu == 2) return y > 0.0f ? y : y * 0.1f;
+    return y < lo ? lo : y;
+  };
+  auto params = [&](int c, float4& sc, float4& sh, float4& rs, float4& rh) {
+    sc = scale ? reinterpret_cast<const float4*>(scale)[c] : one;
+    sh = shift ? reinterpret_cast<const float4*>(shift)[c] : zero;
+    rs = RES && rscale ? reinterpret_cast<const float4*>(rscale)[c] : one;
+    rh = RES && rshift ? reinterpret_cast<const float4*>(rshift)[c] : zero;
+  };
+  // FIXED: C4 divides the workgroup size, so a thread's float4 index i = i0 + u * kThreads + tid (i0 a multiple of kThreads * kUnroll) has the
+  // same channel group i % C4 = tid % C4 in EVERY step: its four parameter vectors are loaded once.  (Loaded per element they were four more
+  // 16-byte loads beside the two of the data: the NHWC kernel ran at half the NCHW kernel's rate, profiles/r06_conv_layout.md.)
+  float4 sc, sh, rs, rh;
+  if (FIXED) params((int)(threadIdx.x % C4), sc, sh, rs, rh);
+  for (long long i0 = (long long)blockIdx.x * kThreads * kUnroll; i0 < n4; i0 += (long long)gridDim.x * kThreads * kUnroll) {
+    float4 v[kUnroll], r[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const long long i = i0 + u * kThreads + threadIdx.x;
+      v[u] = i < n4 ? x4[i] : zero;
+      if (RES) r[u] = i < n4 ? r4[i] : zero;
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const long long i = i0 + u * kThreads + threadIdx.x;
+      if (i < n4) {
+        if (!FIXED) params((int)(i % C4), sc, sh, rs, rh);
+        float4 y;
+        y.x = f(v[u].x, sc.x, sh.x, RES ? r[u].x : 0.f, rs.x, rh.x); y.y = f(v[u].y, sc.y, sh.y, RES ? r[u].y : 0.f, rs.y, rh.y);
+        y.z = f(v[u].z, sc.z, sh.z, RES ? r[u].z : 0.f, rs.z, rh.z); y.w = f(v[u].w, sc.w, sh.w, RES ? r[u].w : 0.f, rs.w, rh.w);
+        o4[i] = y;
+      }
+    }
+  }
+}
+
+// x [N, h, w, C] -> out [N, 2h, 2w, C] = skip + bilinear x2 (align_corners = False); one thread = 4 channels of one output pixel
+template <bool ADD>
+__global__ __launch_bounds__(kThreads) void upsample2x_add_nhwc(const float* __restrict__ x, const float* skip, float* out, int h, int w,
+                                                                int C4, long long items) {
+  const int H = 2 * h, W = 2 * w;
+  for (long long it = (long long)blockIdx.x * kThreads + threadIdx.x; it < items; it += (long long)gridDim.x * kThreads) {
+    const int c = (int)(it % C4);
+    long long p = it / C4;
+    const int xo = (int)(p % W); p /= W;
+    const int yo = (int)(p % H);
+    const long long n = p / H;
+    const Tap ty = tap2x(yo, h), tx = tap2x(xo, w);
+    const float4* xb = reinterpret_cast<const float4*>(x) + (size_t)n * h * w * C4 + c;
+    const float4 v00 = xb[((size_t)ty.i0 * w + tx.i0) * C4], v01 = xb[((size_t)ty.i0 * w + tx.i1) * C4];
+    const float4 v10 = xb[((size_t)ty.i1 * w + tx.i0) * C4], v11 = xb[((size_t)ty.i1 * w + tx.i1) * C4];
+    auto g = [&](float a00, float a01, float a10, float a11) {
+      return ty.l0 * (tx.l0 * a00 + tx.l1 * a01) + ty.l1 * (tx.l0 * a10 + tx.l1 * a11);
+    };
+    float4 o = {g(v00.x, v01.x, v10.x, v11.x), g(v00.y, v01.y, v10.y, v11.y), g(v00.z, v01.z, v10.z, v11.z), g(v00.w, v01.w, v10.w, v11.w)};
+    if (ADD) {
+      const float4 sk = reinterpret_cast<const float4*>(skip)[it];
+      o.x = sk.x + o.x; o.y = sk.y + o.y; o.z = sk.z + o.z; o.w = sk.w + o.w;
+    }
+    reinterpret_cast<float4*>(out)[it] = o;
+  }
+}
+
+// x [N, H, W, C] -> out [N, Ho, Wo, C] = MaxPool2d(3, 2, 1) of relu(x * scale + shift); one thread = 4 channels of one output pixel
+__global__ __launch_bounds__(kThreads) void affine_relu_maxpool_nhwc(const float* __restrict__ x, const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift, int C4, int H, int W, int Ho, int Wo,
+                                                                     long long items, float* __restrict__ out) {
+  for (long long it = (long long)blockIdx.x * kThreads + threadIdx.x; it < items; it += (long long)gridDim.x * kThreads) {
+    const int c = (int)(it % C4);
+    long long p = it / C4;
+    const int xo = (int)(p % Wo); p /= Wo;
+    const int yo = (int)(p % Ho);
+    const long long n = p / Ho;
+    const float4 sc = scale ? reinterpret_cast<const float4*>(scale)[c] : float4{1.f, 1.f, 1.f, 1.f};
+    const float4 sh = shift ? reinterpret_cast<const float4*>(shift)[c] : float4{0.f, 0.f, 0.f, 0.f};
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    bool nan[4] = {false, false, false, false};
+    const float4* xb = reinterpret_cast<const float4*>(x) + (size_t)n * H * W * C4 + c;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int y = 2 * yo + dy;
+      if (y < 0 || y >= H) continue;
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int xx = 2 * xo + dx;
+        if (xx < 0 || xx >= W) continue;
+        const float4 v = xb[((size_t)y * W + xx) * C4];
+        const float t[4] = {v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          nan[e] = nan[e] || t[e] != t[e];
+          const float a = t[e] < 0.0f ? 0.0f : t[e];
+          best[e] = a > best[e] ? a : best[e];
+        }
+      }
+    }
+    const float qn = __builtin_nanf("");
+    reinterpret_cast<float4*>(out)[it] = float4{nan[0] ? qn : best[0], nan[1] ? qn : best[1], nan[2] ? qn : best[2], nan[3] ? qn : best[3]};
+  }
+}
+
 }  // namespace
+
+static inline unsigned nhwc_grid(long long items, long long per_block) {
+  long long g = (items + per_block - 1) / per_block;
+  if (g > 8192) g = 8192;     // grid-stride beyond that: ~32 workgroups per CU
+  return (unsigned)(g < 1 ? 1 : g);
+}
+
+int launch_channel_affine_nhwc(const float* x, const float* scale, const float* shift, const float* res, const float* rscale,
+                               const float* rshift, int relu, long long rows, int C, float* out, hipStream_t st) {
+  if (!x || !out || rows <= 0 || C <= 0 || (C & 3)) return RMNET_E_INVALID_ARG;
+  if (!res && (rscale || rshift)) return RMNET_E_INVALID_ARG;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(scale) |
+       reinterpret_cast<uintptr_t>(shift) | reinterpret_cast<uintptr_t>(rscale) | reinterpret_cast<uintptr_t>(rshift)) & 15)
+    return RMNET_E_INVALID_ARG;
+  const long long n4 = rows * (C >> 2);
+  const dim3 grid(nhwc_grid(n4, (long long)kThreads * kUnroll));
+  const bool fixed = kThreads % (C >> 2) == 0;      // (every layer of both networks: C = 64 ... 1024)
+#define RMNET_CAN(R, F) hipLaunchKernelGGL((channel_affine_nhwc<R, F>), grid, dim3(kThreads), 0, st, x, scale, shift, res, rscale, rshift, relu, C >> 2, n4, out)
+  if (res) { if (fixed) RMNET_CAN(true, true); else RMNET_CAN(true, false); }
+  else     { if (fixed) RMNET_CAN(false, true); else RMNET_CAN(false, false); }
+#undef RMNET_CAN
+  return check_launch();
+}
+
+int launch_upsample2x_add_nhwc(const float* x, const float* skip, long long N, int C, int h, int w, float* out, hipStream_t st) {
+  if (!x || !out || N <= 0 || C <= 0 || (C & 3) || h <= 0 || w <= 0) return RMNET_E_INVALID_ARG;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(skip)) & 15) return RMNET_E_INVALID_ARG;
+  const long long items = N * 4 * h * w * (C >> 2);
+  const dim3 grid(nhwc_grid(items, kThreads));
+  if (skip)
+    hipLaunchKernelGGL(upsample2x_add_nhwc<true>, grid, dim3(kThreads), 0, st, x, skip, out, h, w, C >> 2, items);
+  else
+    hipLaunchKernelGGL(upsample2x_add_nhwc<false>, grid, dim3(kThreads), 0, st, x, skip, out, h, w, C >> 2, items);
+  return check_launch();
+}
+
+int launch_affine_relu_maxpool_nhwc(const float* x, const float* scale, const float* shift, long long N, int C, int H, int W, float* out,
+                                    hipStream_t st) {
+  if (!x || !out || N <= 0 || C <= 0 || (C & 3) || H <= 0 || W <= 0) return RMNET_E_INVALID_ARG;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15)
+    return RMNET_E_INVALID_ARG;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long long items = N * Ho * Wo * (C >> 2);
+  hipLaunchKernelGGL(affine_relu_maxpool_nhwc, dim3(nhwc_grid(items, kThreads)), dim3(kThreads), 0, st, x, scale, shift, C >> 2, H, W, Ho, Wo,
+                     items, out);
+  return check_launch();
+}
 
 int launch_channel_affine(const float* x, const float* scale, const float* shift, const float* res,
                           const float* rscale, const float* rshift, int relu, long long N, int C,

@@ -219,7 +219,9 @@ class Decoder(nn.Module):
         m3 = self.RF3(r3, m4)
         m2 = self.RF2(r2, m3)
         p2 = self.pred2(F.relu(m2))
-        return F.interpolate(p2, scale_factor=4, mode='bilinear', align_corners=False)
+        # (channels-last runs: back to NCHW HERE, on the 2-channel quarter-resolution map -- the decoder tail kernel reads NCHW planes, and
+        #  converting after the x4 upsample would move 16x the bytes; a no-op for NCHW tensors)
+        return F.interpolate(p2.contiguous(), scale_factor=4, mode='bilinear', align_corners=False)
 
 
 class KeyValue(nn.Module):

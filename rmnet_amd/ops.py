@@ -31,6 +31,21 @@ def _check(t, name, dtype=torch.float32):
         raise RuntimeError('%s must be %s, got %s' % (name, dtype, t.dtype))
 
 
+def _is_cl(t):
+    """True for a 4-D tensor that is channels-last in memory ([N,H,W,C]) and NOT also plain-contiguous (C == 1 or H == W == 1 are both)."""
+    return t.dim() == 4 and not t.is_contiguous() and t.is_contiguous(memory_format=torch.channels_last)
+
+
+def _check_act(t, name):
+    """An activation of the glue kernels: fp32, CUDA, NCHW-contiguous or channels-last."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError('%s must be a CUDA tensor' % name)
+    if t.dtype != torch.float32:
+        raise RuntimeError('%s must be torch.float32, got %s' % (name, t.dtype))
+    if not (t.is_contiguous() or _is_cl(t)):
+        raise RuntimeError('%s must be contiguous (NCHW) or channels-last' % name)
+
+
 def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
@@ -417,29 +432,41 @@ def channel_affine(x, scale=None, shift=None, res=None, res_scale=None, res_shif
     one pass (csrc/epilogue.hip); ``relu``: False, True, or 'leaky' (= LeakyReLU(0.1)).  ``out`` may be
     ``x`` or ``res`` (in place); default: a new tensor.
     Replaces BatchNorm2d(eval) / conv bias / skip add / ReLU sequences around the convolutions."""
-    _check(x, 'x')
+    _check_act(x, 'x')
     if x.dim() != 4:
         raise RuntimeError('x must be [N,C,H,W]')
     N, C, H, W = x.shape
+    cl = _is_cl(x)                  # channels-last activations: the NHWC kernel (same arithmetic; csrc/epilogue.hip)
     for t, n in ((scale, 'scale'), (shift, 'shift'), (res_scale, 'res_scale'), (res_shift, 'res_shift')):
         if t is not None:
             _check(t, n)
             if t.numel() != C:
                 raise RuntimeError('%s must have C = %d elements' % (n, C))
     if res is not None:
-        _check(res, 'res')
+        _check_act(res, 'res')
         if res.shape != x.shape:
             raise RuntimeError('res must have the shape of x')
+        if cl and not res.is_contiguous(memory_format=torch.channels_last):
+            res = res.contiguous(memory_format=torch.channels_last)      # (a skip in the other layout: one conversion)
+        elif not cl and not res.is_contiguous():
+            res = res.contiguous()
     elif res_scale is not None or res_shift is not None:
         raise RuntimeError('res_scale / res_shift without res')
     if out is None:
-        out = torch.empty_like(x)
+        out = torch.empty_like(x)       # (preserves the memory format)
     else:
-        _check(out, 'out')
-        if out.shape != x.shape:
-            raise RuntimeError('out must have the shape of x')
+        _check_act(out, 'out')
+        if out.shape != x.shape or not (out.is_contiguous(memory_format=torch.channels_last) if cl else out.is_contiguous()):
+            raise RuntimeError('out must have the shape and memory format of x')
     lib = _lib.load()
     with torch.cuda.device(x.device):
+        if cl and C % 4 == 0:
+            rc = lib.rmnet_channel_affine_nhwc_f32(_ptr(x), _ptr(scale), _ptr(shift), _ptr(res), _ptr(res_scale), _ptr(res_shift),
+                                                   2 if relu == 'leaky' else (1 if relu else 0), N * H * W, C, _ptr(out), _stream(x.device))
+            _lib.check(rc, 'rmnet_channel_affine_nhwc_f32')
+            return out
+        if cl:
+            raise RuntimeError('channels-last channel_affine needs C % 4 == 0')
         rc = lib.rmnet_channel_affine_f32(_ptr(x), _ptr(scale), _ptr(shift), _ptr(res), _ptr(res_scale),
                                           _ptr(res_shift), 2 if relu == 'leaky' else (1 if relu else 0), N, C, H * W, _ptr(out),
                                           _stream(x.device))
@@ -450,23 +477,33 @@ def channel_affine(x, scale=None, shift=None, res=None, res_scale=None, res_shif
 def upsample2x_add(x, skip=None, out=None):
     """skip + F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False) in one pass
     (csrc/epilogue.hip); ``skip`` None = plain upsample; ``out`` may be ``skip`` (in place)."""
-    _check(x, 'x')
+    _check_act(x, 'x')
     if x.dim() != 4:
         raise RuntimeError('x must be [N,C,h,w]')
     N, C, h, w = x.shape
     shape = (N, C, 2 * h, 2 * w)
+    cl = _is_cl(x) or (skip is not None and _is_cl(skip))
+    fmt = torch.channels_last if cl else torch.contiguous_format
+    if cl:
+        x = x.contiguous(memory_format=torch.channels_last)      # (no copy when it already is)
     if skip is not None:
-        _check(skip, 'skip')
+        _check_act(skip, 'skip')
         if tuple(skip.shape) != shape:
             raise RuntimeError('skip must be [N,C,2h,2w]')
-    if out is None:
-        out = torch.empty(shape, dtype=x.dtype, device=x.device)
+        if cl and not _is_cl(skip):
+            skip = skip.contiguous(memory_format=torch.channels_last)
+    if out is None or (cl and not _is_cl(out)):
+        out = torch.empty(shape, dtype=x.dtype, device=x.device, memory_format=fmt)
     else:
-        _check(out, 'out')
+        _check_act(out, 'out')
         if tuple(out.shape) != shape:
             raise RuntimeError('out must be [N,C,2h,2w]')
     lib = _lib.load()
     with torch.cuda.device(x.device):
+        if cl:
+            rc = lib.rmnet_upsample2x_add_nhwc_f32(_ptr(x), _ptr(skip), N, C, h, w, _ptr(out), _stream(x.device))
+            _lib.check(rc, 'rmnet_upsample2x_add_nhwc_f32')
+            return out
         rc = lib.rmnet_upsample2x_add_f32(_ptr(x), _ptr(skip), N, C, h, w, _ptr(out), _stream(x.device))
     _lib.check(rc, 'rmnet_upsample2x_add_f32')
     return out
@@ -497,18 +534,26 @@ def soft_aggregate(dec, obj_begin, K, pad, want_prob=False):
 def affine_relu_maxpool(x, scale=None, shift=None):
     """max_pool2d(relu(x * scale[c] + shift[c]), 3, stride=2, padding=1) in one pass (csrc/epilogue.hip):
     the ResNet stem's bn1 -> relu -> maxpool without the full-resolution intermediate."""
-    _check(x, 'x')
+    _check_act(x, 'x')
     if x.dim() != 4:
         raise RuntimeError('x must be [N,C,H,W]')
     N, C, H, W = x.shape
+    cl = _is_cl(x) and C % 4 == 0
+    if _is_cl(x) and not cl:
+        x = x.contiguous()
     for t, n in ((scale, 'scale'), (shift, 'shift')):
         if t is not None:
             _check(t, n)
             if t.numel() != C:
                 raise RuntimeError('%s must have C = %d elements' % (n, C))
-    out = torch.empty(N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1, dtype=x.dtype, device=x.device)
+    out = torch.empty(N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1, dtype=x.dtype, device=x.device,
+                      memory_format=torch.channels_last if cl else torch.contiguous_format)
     lib = _lib.load()
     with torch.cuda.device(x.device):
+        if cl:
+            rc = lib.rmnet_affine_relu_maxpool_nhwc_f32(_ptr(x), _ptr(scale), _ptr(shift), N, C, H, W, _ptr(out), _stream(x.device))
+            _lib.check(rc, 'rmnet_affine_relu_maxpool_nhwc_f32')
+            return out
         rc = lib.rmnet_affine_relu_maxpool_f32(_ptr(x), _ptr(scale), _ptr(shift), N, C, H, W, _ptr(out),
                                                _stream(x.device))
     _lib.check(rc, 'rmnet_affine_relu_maxpool_f32')

@@ -114,6 +114,17 @@ class RMNet(nn.Module):
         fold_batchnorm_(self.encoder_query)
         return self
 
+    def channels_last(self):
+        """Both convolution stacks in channels_last memory format ([N,H,W,C] in memory): MIOpen's NHWC kernels then run without the layout
+        transposes that wrap them on NCHW tensors, and the fused glue kernels take their channels-last variants (csrc/epilogue.hip) -- +7 %
+        frames/s on the 480p workload (profiles/r06_conv_layout.md).  Same parameters, same state dict, same results up to the convolutions'
+        own rounding.  ATen hands channels_last tensors to MIOpen as NHWC only when PYTORCH_MIOPEN_SUGGEST_NHWC=1 is in the environment
+        BEFORE the first convolution runs: set here if it is not set at all.  The HIP kernels of the read path keep their NCHW interfaces
+        (keys / values / read-out are converted at the boundary: small tensors)."""
+        import os
+        os.environ.setdefault('PYTORCH_MIOPEN_SUGGEST_NHWC', '1')
+        return self.to(memory_format=torch.channels_last)
+
     def fuse_epilogues(self, enable=True):
         """Run BatchNorm(eval) / conv bias / skip add / ReLU as ONE pass per convolution
         (rmnet_channel_affine_f32) in both encoders and the decoder.  Parameters and state dict are

@@ -637,6 +637,64 @@ def test_fused_epilogues_match_the_module_graph(oracle_mod):
         assert float((fused(frames, masks, flows, n_objects, 1) - a).abs().max()) < 1e-3
 
 
+@pytest.mark.parametrize('N,C,H,W', [(2, 8, 5, 6), (1, 64, 30, 54), (3, 4, 7, 9), (2, 256, 12, 20), (1, 12, 6, 5)])
+def test_channels_last_glue_kernels_are_the_nchw_kernels(N, C, H, W):
+    """[r6] The channels-last entries (rmnet_channel_affine_nhwc_f32, rmnet_upsample2x_add_nhwc_f32, rmnet_affine_relu_maxpool_nhwc_f32) compute
+    exactly what the NCHW entries compute -- same expressions, same rounding: bit-identical outputs on the same values in the other layout,
+    incl. in-place use, a skip in the other layout, NaN propagation in the max-pool and LeakyReLU."""
+    from rmnet_amd import ops
+    g = torch.Generator().manual_seed(N * 100 + C)
+    x = torch.randn(N, C, H, W, generator=g).to(dev())
+    res = torch.randn(N, C, H, W, generator=g).to(dev())
+    sc, sh = (torch.rand(C, generator=g) + 0.5).to(dev()), torch.randn(C, generator=g).to(dev())
+    rs, rh = (torch.rand(C, generator=g) + 0.5).to(dev()), torch.randn(C, generator=g).to(dev())
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    for kw in (dict(relu=True), dict(relu=False), dict(relu='leaky'), dict(res=res, relu=True), dict(res=res, res_scale=rs, res_shift=rh, relu=True)):
+        want = ops.channel_affine(x, sc, sh, **kw)
+        kw_cl = dict(kw, res=cl(kw['res'])) if 'res' in kw else kw
+        got = ops.channel_affine(cl(x), sc, sh, **kw_cl)
+        assert got.is_contiguous(memory_format=torch.channels_last) and torch.equal(got, want), kw.keys()
+        if 'res' in kw:                                       # a skip in the OTHER layout is converted, not misread
+            assert torch.equal(ops.channel_affine(cl(x), sc, sh, **kw), want)
+    t = cl(x.clone())
+    assert ops.channel_affine(t, None, sh, relu=True, out=t) is t and torch.equal(t, ops.channel_affine(x, None, sh, relu=True))     # in place, no scale
+    skip = torch.randn(N, C, 2 * H, 2 * W, generator=g).to(dev())
+    want = ops.upsample2x_add(x, skip)
+    got = ops.upsample2x_add(cl(x), cl(skip))
+    assert got.is_contiguous(memory_format=torch.channels_last) and torch.equal(got, want)
+    assert torch.equal(ops.upsample2x_add(cl(x)), ops.upsample2x_add(x))
+    xn = x.clone()
+    xn[0, 1, 2, 3] = float('nan')
+    want = ops.affine_relu_maxpool(xn, sc, sh)
+    got = ops.affine_relu_maxpool(cl(xn), sc, sh)
+    assert got.is_contiguous(memory_format=torch.channels_last) and got.shape == want.shape
+    assert torch.equal(torch.isnan(got), torch.isnan(want)) and torch.equal(torch.nan_to_num(got), torch.nan_to_num(want))
+
+
+def test_channels_last_loop_meets_the_bar(oracle_mod):
+    """[r6] The frame loop with both networks in channels_last memory format (MIOpen's NHWC kernels, no layout transposes) and the fused glue
+    kernels ON -- bench.py --channels-last -- against the CPU path on a live-boundary clip: the same bars as the NCHW loop
+    (test_live_boundary_clips_meet_the_bar_in_every_arithmetic), and within fp32 convolution rounding of the NCHW loop itself."""
+    prod, ref = _nets(oracle_mod, 'auto')
+    name = 'live480-a'
+    frames, masks, flows, n_objects, every, delta = lf.make_clip(name)
+    lf.shift_foreground_bias(prod, delta)
+    lf.shift_foreground_bias(ref, delta)
+    prod.fuse_epilogues()
+    est_cpu, log_cpu = _cpu_path(oracle_mod, ref, name, frames, masks, flows, n_objects, every)
+    with torch.no_grad():
+        est_n, log_n = prod(frames, masks, flows, n_objects, every, return_logits=True)
+        prod = prod.to(memory_format=torch.channels_last)
+        assert prod.encoder_query.conv1.weight.is_contiguous(memory_format=torch.channels_last)
+        est, logits = prod(frames, masks, flows, n_objects, every, return_logits=True)
+    est, logits = est.cpu(), logits.cpu()
+    iou, gap = lf.label_iou(est, est_cpu), lf.logit_gap(logits, log_cpu)
+    _table('%s channels_last auto: IoU %.5f  max live fg-logit diff %.2e; vs the NCHW loop: max prob diff %.2e' % (
+        name, iou, gap, float((est - est_n.cpu()).abs().max())))
+    assert iou >= 0.999 and gap <= LIVE_LOGIT_BAR, (iou, gap)
+    assert lf.label_iou(est, est_n.cpu()) >= 0.9995
+
+
 @pytest.mark.parametrize('N,C,h,w', [(2, 3, 5, 6), (1, 8, 30, 54), (1, 2, 7, 9), (1, 1, 1, 1), (4, 16, 60, 108)])
 def test_upsample2x_add_is_torch_bilinear(N, C, h, w):
     """rmnet_upsample2x_add_f32 == skip + F.interpolate(x, scale_factor=2, 'bilinear',
@@ -1943,18 +2001,20 @@ def _table(line):
 LIVE_LOGIT_BAR = 2e-2
 
 
-@pytest.mark.parametrize('name,mode', [(n, m) for n in ('live480-a', 'live480-b') for m in ('auto', 'exact', 'split', 'qx', 'f16')] + [('live480-c', m) for m in ('auto', 'exact', 'f16')] +
+@pytest.mark.parametrize('name,mode', [(n, m) for n in ('live480-a', 'live480-b') for m in ('auto', 'auto-cl', 'exact', 'split', 'qx', 'f16')] + [('live480-c', m) for m in ('auto', 'auto-cl', 'exact', 'f16')] + [('live720', 'auto-cl')] +
                          [('live720', 'auto'), ('live720', 'exact'), ('live720', 'qx')])      # (720x1280: the resolution of configs[3] / [4])
 def test_live_boundary_clips_meet_the_bar_in_every_arithmetic(name, mode, oracle_mod):
     """The north star's bar -- mask IoU within 1e-3 of the CPU path -- on one-object 480x854 (and 720x1280) clips whose masks HAVE a boundary
     (cover 10-60 %, >= 1 % of the pixels within 0.1 of the threshold on every frame: asserted), for the GPU loop with the
     exact-fp32 read, the three bank arithmetics and the default.  Also compared: the logits (LIVE_LOGIT_BAR) and the
     probabilities.  That this comparison CAN fail is test_mutated_memory_read_fails_the_parity_metric."""
-    prod, ref = _nets(oracle_mod, 'auto' if mode == 'exact' else mode)
+    prod, ref = _nets(oracle_mod, 'auto' if mode in ('exact', 'auto-cl') else mode)
     frames, masks, flows, n_objects, every, delta = lf.make_clip(name)
     lf.shift_foreground_bias(prod, delta)
     lf.shift_foreground_bias(ref, delta)
     prod.fuse_epilogues()
+    if mode == 'auto-cl':          # [r6] bench.py's configuration: both networks channels_last (MIOpen NHWC kernels), channels-last glue kernels
+        prod = prod.channels_last()
     est_cpu, log_cpu = _cpu_path(oracle_mod, ref, name, frames, masks, flows, n_objects, every)
     lf.assert_live(est_cpu, name)
     with torch.no_grad():
