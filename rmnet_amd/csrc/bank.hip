@@ -1187,6 +1187,200 @@ constexpr float kTileUs = 1.75f, kTileUsF16 = 0.55f, kLaunchUs = 12.0f;   // til
 static_assert(kSplitMax * kQT * 4 <= 2 * kPbuf, "merge weights live in the P buffers");
 static_assert(kConsumers * 16 * 65 * 4 + 2 * 4 * kQT * 4 <= 8 * kKbuf, "epilogue scratch lives in the K ring");
 
+// =========================================== [r6] merge of a pair by ALL its workgroups ===========================================
+// A pair cut into nsp segments has nsp published partials (O as 128 fragment UNITS of 16 channels x 16 queries = 1 KB each, m, l).
+// Until round 5 the pair's last arriver merged them alone: nsp - 1 dependent trips to memory of 128 KB each, 2.2-2.6 us per trip
+// (profiles/r04_f_dropin_breakdown.md: 20-23 us of a 51 us dense read while 230 workgroups had nothing to do).  Now the workgroup
+// at position s of the pair owns the units U = s, s + n, s + 2 n, ... (n = the pair's aligned column blocks -- the workgroups that
+// run ONE segment -- or all its segments if it has none; spread over the workgroup's eight consumer waves), waits until all nsp
+// partials are published, and reads its units from EVERY slot in one batch of independent loads, issued before the weights exist:
+// the merge is one trip to memory whatever nsp is.  The sum runs over the slots in slot order -- the read-out does not depend on who arrived when.
+// The wait needs the pair's other workgroups to be running or finished; they never wait inside their walks, the launch has at most
+// one workgroup per CU (kSplitTargetSlots <= 256 CUs), and the poll is bounded (time-out word + NaN read-out, never a hang).
+struct MergeJob {
+  int o, qt, sself;          // object (absolute), query tile, this workgroup's position among the pair's segments
+  int nqt, njt, C, own;      // the object's plan: query tiles, memory tiles, chunk length, kind of plan (bank_chunks)
+  int slot_obj;              // the object's first partial slot
+  Rect qr;                   // query box
+  float n_out;               // masked memory cells of the object
+  // (the launch's pointers BY VALUE: a reference to the kernel's argument block would move the whole block to the stack)
+  float *ws_o, *ws_ml, *out, *ml_out;
+  int32_t *cnt, *ovf;
+  int hw, w;
+};
+// (NOT inlined: inside bk_main its 24 loads in flight pushed hipcc into spilling inside the tile walks)
+template <int kTerms>
+__device__ __forceinline__ void merge_pair(const MergeJob m, char* Kl_, char* Pl_, int* sgave) {
+  const int tid = threadIdx.x, hw = m.hw;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave < kProducers;
+  const int ln = tid & 63, l15 = ln & 15, g = ln >> 4;
+  const BankChunks bc = bank_chunks(m.nqt, m.njt, m.C, seg_cost_of(kTerms), m.own);
+  const PairSlots ps = pair_slots(m.slot_obj, m.nqt, bc, m.qt);
+  const int nsp = ps.count, qt = m.qt, sself = m.sself;
+  const int nown = ps.na > 0 ? ps.na : nsp;               // the pair's merging workgroups: its aligned column blocks if it has any (a
+                                                          // remainder chunk runs several segments; it only publishes), else all
+  const int o = m.o;
+  const Rect qr = m.qr;
+  const int Mq = qr.area();
+  const float n_out = m.n_out;                            // masked memory cells: S = 0, V = 0 (file header)
+  auto sld = [](const int& x) { return __builtin_amdgcn_readfirstlane(x); };   // LDS value -> SGPR
+  constexpr size_t kSlotF = (size_t)kDo * kQT;            // floats per partial slot
+  auto slot_rsrc = [&](int slot) {                        // buffer descriptor of a partial slot (wave-uniform base)
+    float* base = m.ws_o + (size_t)slot * kSlotF;
+    const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(base));
+    const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(base) >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((uintptr_t)bhi << 32) | blo), 0,
+                                             (int)(kSlotF * 4), 0x00020000);
+  };
+  float* Wt = reinterpret_cast<float*>(Pl_);              // [slot of the pair][query]: 2^(m_s - m_tot)   (16 KB: the P buffers)
+  float* red = reinterpret_cast<float*>(Kl_);             // [4][64] partial maxima                       (the idle K ring)
+  float* red2 = red + 4 * kQT;                            // [4][64] partial sums
+  int* left = m.cnt + 2 * ((size_t)o * bank_nqt_max(hw) + qt);
+  int* done = left + 1;
+  if (tid == 0) {
+    int polls = 0;
+    bool gave_up = false;
+    while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nsp) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++polls > (1 << 21)) { gave_up = true; break; }
+    }
+    *sgave = gave_up ? 1 : 0;
+    if (gave_up) {   // (a workgroup of the pair never ran.  Never hang the GPU: count it in the time-out word, make the bank say
+      atomicAdd(m.ovf + 1, 1);                                          // "do not trust me" and leave the counters alone; the
+      atomicOr(m.ovf, kBankTimeout);                                    // launcher clears the control block before every read)
+    } else if (__hip_atomic_fetch_add(left, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nown - 1) {
+      __hip_atomic_store(left, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the last one to see the pair complete: clean
+      __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // counters for the next read
+    }
+  }
+  __syncthreads();                                                                // M1: all partials of the pair are in memory
+  const float poison = sld(*sgave) ? __builtin_nanf("") : kBankValueUnscale;
+  //      Producers: the pair's weights.  thread (sl = wave, qi = lane): query qi, slots sl, sl + 4, ...
+  //      The partials were stored write-through and are read with sc1 loads (L2-coherent at agent scope: no acquire fence, no L1
+  //      invalidate needed).
+  constexpr int kMl = 4;
+  float m_r[kMl], l_r[kMl];
+  auto ml_load = [&](int sj, int qi, float& m_, float& l_) {
+    const float* e = m.ws_ml + (size_t)ps.slot(sj) * 2 * kQT;
+    m_ = __hip_atomic_load(e + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    l_ = __hip_atomic_load(e + kQT + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  if (producer) {
+    const int qi = ln, sl = wave;
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < kMl; ++j) {
+      const int sj = sl + 4 * j;
+      m_r[j] = -INFINITY; l_r[j] = 0.0f;
+      if (sj < nsp) ml_load(sj, qi, m_r[j], l_r[j]);
+      mloc = fmaxf(mloc, m_r[j]);
+    }
+    for (int sj = sl + 4 * kMl; sj < nsp; sj += 4) {
+      float ms, ls;
+      ml_load(sj, qi, ms, ls);
+      mloc = fmaxf(mloc, ms);
+    }
+    red[sl * kQT + qi] = mloc;
+    __syncthreads();                                                              // M2
+    float mtot = fmaxf(fmaxf(red[qi], red[kQT + qi]), fmaxf(red[2 * kQT + qi], red[3 * kQT + qi]));
+    if (n_out > 0.0f) mtot = fmaxf(mtot, 0.0f);          // the masked memory cells have S = 0
+    float lloc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kMl; ++j) {
+      const int sj = sl + 4 * j;
+      const float wgt = __builtin_amdgcn_exp2f(m_r[j] - mtot);     // (-inf for a slot that does not exist: 0)
+      if (sj < nsp) Wt[sj * kQT + qi] = wgt;
+      lloc += l_r[j] * wgt;
+    }
+    for (int sj = sl + 4 * kMl; sj < nsp; sj += 4) {
+      float ms, ls;
+      ml_load(sj, qi, ms, ls);
+      const float wgt = __builtin_amdgcn_exp2f(ms - mtot);
+      Wt[sj * kQT + qi] = wgt;
+      lloc += ls * wgt;
+    }
+    // (the closed-form term N_out * 2^(-m_tot) of the masked memory cells rides in group 0's partial sum)
+    red2[sl * kQT + qi] = lloc + (sl == 0 && n_out > 0.0f ? n_out * __builtin_amdgcn_exp2f(-mtot) : 0.0f);
+    __syncthreads();                                                              // M3
+    if (m.ml_out && wave == 0 && sself == 0) {   // chained reads (> kMaxT frames): the state of this pair's queries
+      const int nq = qt * kQT + ln;
+      if (nq < Mq) {
+        const int rw = qr.width(), ry = nq / rw;
+        const int cell = (qr.cy0 + ry) * m.w + qr.cx0 + (nq - ry * rw);
+        float* ml = m.ml_out + (size_t)o * 2 * hw;
+        ml[cell] = mtot;
+        ml[hw + cell] = red2[ln] + red2[kQT + ln] + red2[2 * kQT + ln] + red2[3 * kQT + ln];
+      }
+    }
+    return;
+  }
+  // ---- consumers: this workgroup's units.  Unit U = 4 * (channel tile) + (query group); wave wv takes the workgroup's units
+  //      number wv, wv + 8, ...  UN units x SN slots are in flight at a time (static register arrays; the shape follows nsp).
+  //      The first batch of loads is issued BEFORE the weights exist (barriers M2 / M3 are passed behind it).
+  const int wv = wave - kProducers;
+  const int n_s = plan_div(128 - sself + nown - 1, nown);   // units of this workgroup
+  constexpr int kOOB = 0x40000000;                       // a byte offset no slot reaches: the buffer unit returns 0 / drops the access
+  bool synced = false;
+  auto weights_ready = [&]() {
+    if (!synced) { __syncthreads(); __syncthreads(); synced = true; }             // M2, M3 (consumer side)
+  };
+  auto merge_units = [&](auto un_tag, auto sn_tag) {
+    constexpr int UN = decltype(un_tag)::value, SN = decltype(sn_tag)::value;
+    for (int i0 = 0; wv + 8 * i0 < n_s; i0 += UN) {
+      f32x4 r[UN];
+      int U[UN];
+#pragma unroll
+      for (int ui = 0; ui < UN; ++ui) {
+        const int j = wv + 8 * (i0 + ui);
+        U[ui] = j < n_s ? sself + j * nown : -1;
+        r[ui] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      for (int s0 = 0; s0 < nsp; s0 += SN) {
+        u32x4 v[UN][SN];
+#pragma unroll
+        for (int sj = 0; sj < SN; ++sj) {
+          const bool sv = s0 + sj < nsp;
+          const __amdgpu_buffer_rsrc_t rs = slot_rsrc(ps.slot(sv ? s0 + sj : nsp - 1));
+#pragma unroll
+          for (int ui = 0; ui < UN; ++ui)
+            v[ui][sj] = __builtin_amdgcn_raw_buffer_load_b128(rs, (sv && U[ui] >= 0) ? U[ui] * 1024 + ln * 16 : kOOB, 0, 16 /* sc1 */);
+        }
+        weights_ready();
+#pragma unroll
+        for (int sj = 0; sj < SN; ++sj) {
+          const int sw = min(s0 + sj, nsp - 1) * kQT + l15;          // (a slot past the pair: its loads returned 0)
+#pragma unroll
+          for (int ui = 0; ui < UN; ++ui) r[ui] += Wt[sw + (U[ui] & 3) * 16] * __builtin_bit_cast(f32x4, v[ui][sj]);
+        }
+      }
+#pragma unroll
+      for (int ui = 0; ui < UN; ++ui) {
+        if (U[ui] < 0) continue;                                       // (wave-uniform)
+        const int q = (U[ui] & 3) * 16 + l15, nq = qt * kQT + q;
+        const float iq = poison / (red2[q] + red2[kQT + q] + red2[2 * kQT + q] + red2[3 * kQT + q]);
+        if (nq < Mq) {
+          const int rw = qr.width(), ry = nq / rw;
+          const int cell = (qr.cy0 + ry) * m.w + qr.cx0 + (nq - ry * rw);
+          // (a store instruction covers 16 consecutive compacted queries of four channel rows)
+          float* __restrict__ outo = m.out + ((size_t)o * 2 * kDo + 4 * (U[ui] >> 2) * 4 + 4 * g) * hw + cell;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) outo[(size_t)e * hw] = r[ui][e] * iq;
+        }
+      }
+    }
+  };
+  using std::integral_constant;
+  if (nsp == 2) merge_units(integral_constant<int, 8>{}, integral_constant<int, 2>{});
+  else if (nsp == 3) merge_units(integral_constant<int, 6>{}, integral_constant<int, 3>{});
+  else if (nsp == 4) merge_units(integral_constant<int, 4>{}, integral_constant<int, 4>{});
+  else if (nsp <= 6) merge_units(integral_constant<int, 4>{}, integral_constant<int, 6>{});
+  else if (nsp <= 8) merge_units(integral_constant<int, 3>{}, integral_constant<int, 8>{});
+  else if (nsp <= 12) merge_units(integral_constant<int, 2>{}, integral_constant<int, 12>{});
+  else merge_units(integral_constant<int, 1>{}, integral_constant<int, 20>{});
+  weights_ready();                                         // (a wave without units)
+}
+
 // Launch-wide work list (stream-K with L2-friendly order).  Per object the work is the matrix
 // nqt(o) query tiles x njt(o) memory tiles.  ONE chunk length C (tiles per workgroup) is chosen for
 // the whole launch so that the chunks of all objects fill the compute workgroups, whatever the box sizes.
@@ -1198,10 +1392,10 @@ static_assert(kConsumers * 16 * 65 * 4 + 2 * 4 * kQT * 4 <= 8 * kKbuf, "epilogue
 //   * the remainder block of R = njt mod C tiles: its nqt * R tiles, query-tile-major, are cut into
 //     chunks of C again; such a chunk crosses query tiles and runs several SEGMENTS (all inside the
 //     same R <= C tile columns, which fit the L2).
-// Every segment owns a partial slot.  A segment ends with a ticket on its pair's arrival counter: the early arrivers
-// publish their partial (O, m, l) with write-through stores and count themselves done; the LAST arriver keeps its
-// partial in registers, waits until the others are done (they are past their loops: the wait cannot deadlock,
-// whatever is resident), merges the pair and writes its read-out.
+// Every segment owns a partial slot.  The only segment of a pair writes the pair's read-out from its registers.  One of several
+// publishes its partial (O, m, l) with write-through stores and counts itself done on the pair's counter; when a workgroup's
+// walks are over it merges, for every pair it holds a segment of, ITS share of the pair's 128 fragment units from all the pair's
+// partials (merge_pair below: [r6] until round 5 the pair's last arriver merged alone, one 128 KB trip to memory per partial).
 template <int kTerms>
 __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
@@ -1288,55 +1482,40 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
       aside = min(aside, a.target / 4);
       target = a.target - aside;
     }
-    // smallest chunk length whose chunks fit `target` workgroups (sum_o nch(o) shrinks as C grows).  The candidates are the
-    // sequence C, next(C), next(next(C)), ...; FOUR of them are priced per round (independent divisions and reductions
-    // overlap): this search sits on the critical path of every workgroup, and one candidate at a time with shuffle
-    // reductions cost 0.45 us per step, 3 us at the bench launch (r04 time line).
+    // [r6] The plan (common.h: bank_plan_pick).  64 candidates of each kind are priced AT ONCE, one per lane, in one loop over the
+    // objects (the search sits on the critical path of every workgroup: until round 5 it walked the candidates four at a time with
+    // wave reductions -- 5-6 rounds at the bench launch): lane i prices the equalised plan with i + 1 column blocks of the
+    // longest object and the plain plan at chunk length Clo + i * step (from the even cut to the longest object).
     constexpr int kSC = seg_cost_of(kTerms);
     constexpr int kCq = kTerms != 3 ? 2 : 1;              // (fp16 modes: a step is two tiles, an odd chunk wastes half of one)
-    auto next_c = [](int c) { return c + (1 + (c >> 5) + kCq - 1) / kCq * kCq; };
-    // chunks of this lane's object at chunk length c = bank_chunks(nqt, njt, c, kSC).nch with the two integer divisions done in
-    // fp32 (all operands < 2^22: the quotient is off by at most one, fixed up) -- ~15 instructions instead of ~80
-    auto fdiv = [](int x, int c, float rc) {
-      int q = (int)((float)x * rc);
-      const int r = x - q * c;
-      q += (r >= c) - (r < 0);
-      return q;
-    };
-    auto nch_at = [&](int c) {
-      const float rc = __builtin_amdgcn_rcpf((float)c);
-      const int nfull = fdiv(njt, c, rc), R = njt - nfull * c;
-      const int nrem = R > 0 && nqt > 0 ? fdiv(nqt * (R + kSC) - kSC + c - 1, c, rc) : 0;
-      return nqt * nfull + nrem;
-    };
-    int C0 = max(W < (1 << 22) ? plan_div(W + target - 1, target) : (W + target - 1) / target, bank_chunk_min(njt_max));
-    C0 = (C0 + kCq - 1) / kCq * kCq;
-    for (int it = 0; it < 256; ++it) {
-      const int c1 = next_c(C0), c2 = next_c(c1), c3 = next_c(c2);
-      const int n0 = wave_sum_fast(nch_at(C0)), n1 = wave_sum_fast(nch_at(c1));
-      const int n2 = wave_sum_fast(nch_at(c2)), n3 = wave_sum_fast(nch_at(c3));
-      if (n0 <= target) break;
-      if (n1 <= target) { C0 = c1; break; }
-      if (n2 <= target) { C0 = c2; break; }
-      if (n3 <= target) { C0 = c3; break; }
-      C0 = next_c(c3);
+    const int cmin = (bank_chunk_min(njt_max) + kCq - 1) / kCq * kCq;
+    const int ce = bank_eq_chunk_len(njt_max, tid + 1, kCq, cmin);
+    int Clo = max(W < (1 << 22) ? plan_div(W + target - 1, target) : (W + target - 1) / target, cmin);
+    Clo = (Clo + kCq - 1) / kCq * kCq;
+    const int Chi = max((njt_max + kCq - 1) / kCq * kCq, Clo);
+    const int step = (max(plan_div(Chi - Clo + 62, 63), 1) + kCq - 1) / kCq * kCq;
+    const int cp = Clo + tid * step;
+    const int nqe = njt > 0 ? nqt : 0;
+    const int P = wave_sum_fast(nqe);
+    int C0 = Clo, blocks = 0;
+    if (P <= target) {
+      int me = 0, mp = 0;
+      for (int o = 0; o < ng; ++o) {    // (lane o holds object o's tile counts: a readlane per object, no LDS round trip)
+        const int nq = __builtin_amdgcn_readlane(nqt, o), nj = __builtin_amdgcn_readlane(njt, o);
+        me += bank_eq_count(nq, nj, ce);
+        mp += bank_chunks(nq, nj, cp, kSC, 0).nch;
+      }
+      const unsigned long long f1 = __ballot(me <= target), fp = __ballot(mp <= target);
+      const int l1 = f1 ? 63 - __builtin_clzll(f1) : -1;
+      const int c1 = l1 >= 0 ? __builtin_amdgcn_readlane(ce, l1) : 0;
+      const BankPlanPick pk = bank_plan_pick(c1, c1 >= njt_max, fp ? __builtin_amdgcn_readlane(cp, __builtin_ctzll(fp)) : 0, kSC, kTerms);
+      C0 = pk.C > 0 ? pk.C : Chi;
+      blocks = pk.blocks;
+      if (!blocks && wave_sum_fast(bank_chunks(nqt, njt, C0, kSC, 1).nch) <= target) blocks = 1;   // short objects as blocks of their own (common.h)
     }
-    // EQUALISED column blocks (common.h: no remainder chunks, a pair has ceil(njt / C) partials) if they fit the workgroups at C0 or one
-    // of the next two candidates; else short objects as blocks of their own if that fits; else the plain plan.
-    int blocks = 0;
-    {
-      auto neq_at = [&](int c) { return nqt * (njt > 0 ? fdiv(njt + c - 1, c, __builtin_amdgcn_rcpf((float)c)) : 0); };
-      const int c1 = next_c(C0), c2 = next_c(c1);
-      const int m0 = wave_sum_fast(neq_at(C0)), m1 = wave_sum_fast(neq_at(c1)), m2 = wave_sum_fast(neq_at(c2));
-      const int ceq = m0 <= target ? C0 : m1 <= target ? c1 : (m2 <= target && kTerms != 3) ? c2 : 0;   // (split mode: a tile costs 3x, one candidate less)
-      if (ceq) { C0 = ceq; blocks = 2; }
-    }
-    if (!blocks && wave_sum_fast(bank_chunks(nqt, njt, C0, kSC, 1).nch) <= target) blocks = 1;   // short objects as blocks of their own (common.h)
     // [r6] more pairs than workgroups: ROUNDS of aligned chunks (common.h: bank_round_chunk_len) -- every object gets its own chunk
     // length, every chunk is one segment, a workgroup runs chunk c, c + G, c + 2 G, ...
     int Cobj = C0;
-    const int nqe = njt > 0 ? nqt : 0;
-    const int P = wave_sum_fast(nqe);
     if (P > target) {
       const int ps = wave_scan_incl_fast(nqe);
       const int Pw = wave_max_fast(ps <= plan_div(P, target) * target ? ps : 0);
@@ -1361,6 +1540,46 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     pr[4] = r.cx0; pr[5] = r.cx1; pr[6] = r.cy0; pr[7] = r.cy1;
     pr[8] = a.slot0 + o_sb[og]; pr[9] = o_c[og]; pr[10] = nchunks; pr[11] = 1;
   }
+
+  constexpr size_t kSlotF = (size_t)kDo * kQT;            // floats per partial slot
+  auto slot_rsrc = [&](int slot) {                        // buffer descriptor of a partial slot (wave-uniform base)
+    float* base = a.ws_o + (size_t)slot * kSlotF;
+    const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(base));
+    const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(base) >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((uintptr_t)bhi << 32) | blo), 0,
+                                             (int)(kSlotF * 4), 0x00020000);
+  };
+
+  // [r6] merge pass over chunk c (after the walks): the same chunk -> segments enumeration as compute() below, one merge_pair per
+  // segment whose pair has several
+  auto merge_chunk = [&](const int c) {
+    const int li = tid & 63;
+    const unsigned long long le = __ballot((li < ng ? o_cb[li] : 0x7fffffff) <= c);
+    const int og = le ? 63 - __builtin_clzll(le) : 0;
+    MergeJob m;
+    m.o = a.obj0 + og;
+    m.nqt = sld(o_nqt[og]); m.njt = sld(o_njt[og]); m.C = sld(o_c[og]); m.own = sld(plan_own);
+    m.slot_obj = a.slot0 + sld(o_sb[og]);
+    m.qr = Rect{sld(o_rect[og][0]), sld(o_rect[og][1]), sld(o_rect[og][2]), sld(o_rect[og][3])};
+    m.n_out = (float)(T_ * hw - sld(o_m[og]));
+    m.ws_o = a.ws_o; m.ws_ml = a.ws_ml; m.out = a.out; m.ml_out = a.ml_out; m.cnt = b.cnt; m.ovf = b.ovf; m.hw = hw; m.w = b.w;
+    const BankChunks bc = bank_chunks(m.nqt, m.njt, m.C, seg_cost_of(kTerms), m.own);
+    const int cl = c - sld(o_cb[og]);
+    if (cl < m.nqt * bc.nfull) {
+      const int blk = plan_div(cl, m.nqt);
+      m.qt = cl - blk * m.nqt; m.sself = blk;
+      if (bc.nfull >= 2) merge_pair<kTerms>(m, Kl_, Pl_, &sgave);    // (exactly one aligned block: merged by it in place, run_segment)
+      return;
+    }
+    const int cr = cl - m.nqt * bc.nfull;
+    const int u0 = cr * m.C, u1 = u0 + m.C, span = bc.R + bc.sc;
+    if (bc.nfull > 0) return;                             // (pairs with aligned column blocks are merged by those)
+    for (int qt = plan_div(u0, span); qt < m.nqt && qt * span < u1; ++qt) {
+      if (min(u1 - qt * span, bc.R) <= max(u0 - qt * span, 0)) continue;
+      m.qt = qt; m.sself = bc.nfull + cr - plan_div(qt * span, m.C);
+      if (pair_slots(m.slot_obj, m.nqt, bc, qt).count > 1) merge_pair<kTerms>(m, Kl_, Pl_, &sgave);
+    }
+  };
 
   // =========================================== compute: this workgroup's chunk ===========================================
   auto compute = [&](const int c) {
@@ -1454,7 +1673,6 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     const int l15 = ln & 15, g = ln >> 4;
     const PairSlots ps = pair_slots(slot_obj, nqt, bc, wk.qt);
     const int nsp = ps.count;
-    constexpr size_t kSlotF = (size_t)kDo * kQT;          // floats per partial slot
     // epilogue scratch: merge weights in the P buffers (16 KB), the rest in the (now idle) K ring
     float* Wt = reinterpret_cast<float*>(Pl_);            // [slot of the pair][query]: 2^(m_s - m_tot)
     float* Tw = reinterpret_cast<float*>(Kl_);            // [consumer wave][16 channels][65]: transposes
@@ -1463,64 +1681,58 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     float* Msh = Al;                                      // own (m, l) of the 64 queries
     float* Lsh = Al + kQT;
     const int dt0 = kCDT * (wave - kProducers);           // (consumers) first channel tile of this wave
-    auto slot_rsrc = [&](int slot) {                      // buffer descriptor of a partial slot (wave-uniform base)
-      float* base = a.ws_o + (size_t)slot * kSlotF;
-      const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(base));
-      const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(reinterpret_cast<uintptr_t>(base) >> 32));
-      return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((uintptr_t)bhi << 32) | blo), 0,
-                                               (int)(kSlotF * 4), 0x00020000);
-    };
-    if (producer && g == 0) { Msh[wave * 16 + l15] = m_seg; Lsh[wave * 16 + l15] = l_seg; }
-    if (nsp > 1) {
-      int* arrive = b.cnt + 2 * ((size_t)wk.o * bank_nqt_max(hw) + wk.qt);
-      int* done = arrive + 1;
-      if (tid == 0) sflag = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();                                                              // E1: the ticket (and Msh / Lsh)
-      const int ticket = sld(sflag);
-      if (ticket != nsp - 1) {
-        // ---- early arriver: publish with write-through (sc1) stores, drained by every storing wave, THEN count done
-        //      (cdna_hip_programming.md section 6 Guideline 16, recipe R1 in its counter form)
-        if (!producer) {
-          const __amdgpu_buffer_rsrc_t rs = slot_rsrc(wk.slot);
+    // [r6] Who merges a pair of several segments:
+    //   * a pair with exactly ONE aligned column block (the plain plan: one block + remainder chunks): that block's workgroup, HERE, with
+    //     its own partial in registers -- it waits until the remainder segments are published (their workgroups only publish and
+    //     go on: the wait cannot deadlock, whatever is resident) and adds them slot by slot;
+    //   * every other pair (equalised blocks, rounds, remainder-only pairs): all its workgroups (or its aligned ones) together, after
+    //     their walks (merge_pair): this segment publishes and goes on.
+    const bool owner_here = nsp > 1 && ps.na == 1 && sself == 0;
+    if (nsp > 1 && !owner_here) {
+      // ---- publish with write-through (sc1) stores, drained by every storing wave, THEN count it
+      //      (cdna_hip_programming.md section 6 Guideline 16, recipe R1 in its counter form)
+      if (!producer) {
+        const __amdgpu_buffer_rsrc_t rs = slot_rsrc(wk.slot);
 #pragma unroll
-          for (int dt = 0; dt < kCDT; ++dt)
+        for (int dt = 0; dt < kCDT; ++dt)
 #pragma unroll
-            for (int it = 0; it < 4; ++it)
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[dt][it]), rs,
-                                                     (int)(partial_frag_offset(dt0 + dt, it, ln) * 4), 0, 16 /* sc1 */);
-        } else if (g == 0) {
-          float* wm = a.ws_ml + (size_t)wk.slot * 2 * kQT;
-          __hip_atomic_store(wm + wave * 16 + l15, m_seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(wm + kQT + wave * 16 + l15, l_seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                                            // every wave's stores have landed
-        if (tid == 0) __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;                                 // the pair's last arriver merges
+          for (int it = 0; it < 4; ++it)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[dt][it]), rs,
+                                                   (int)(partial_frag_offset(dt0 + dt, it, ln) * 4), 0, 16 /* sc1 */);
+      } else if (g == 0) {
+        float* wm = a.ws_ml + (size_t)wk.slot * 2 * kQT;
+        __hip_atomic_store(wm + wave * 16 + l15, m_seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(wm + kQT + wave * 16 + l15, l_seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      // ---- last arriver: its own partial stays in registers.  Wait for the others' publications: they all hold a
-      //      ticket, i.e. they have left their tile loops and only store -- the wait ends whatever else is (not) resident.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                                            // every wave's stores have landed
+      if (tid == 0)
+        __hip_atomic_fetch_add(b.cnt + 2 * ((size_t)wk.o * bank_nqt_max(hw) + wk.qt) + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (producer && g == 0) { Msh[wave * 16 + l15] = m_seg; Lsh[wave * 16 + l15] = l_seg; }
+    if (owner_here) {
+      int* done = b.cnt + 2 * ((size_t)wk.o * bank_nqt_max(hw) + wk.qt) + 1;
       if (tid == 0) {
         int polls = 0;
         bool gave_up = false;
         while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nsp - 1) {
-          __builtin_amdgcn_s_sleep(4);
-          if (++polls > (1 << 22)) { gave_up = true; break; }
+          __builtin_amdgcn_s_sleep(2);
+          if (++polls > (1 << 21)) { gave_up = true; break; }
         }
         sgave = gave_up ? 1 : 0;
-        if (gave_up) {   // (cannot happen: the others hold a ticket and only store.  Never hang the GPU: count it in the time-out
-          atomicAdd(b.ovf + 1, 1);                                          // word, make the bank say "do not trust me" and leave
-          atomicOr(b.ovf, kBankTimeout);                                    // the counters alone -- late arrivers may still bump them;
-        } else {                                                            // the launcher clears the control block before every read)
-          __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean counters for the next read
-          __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gave_up) {   // (a workgroup of the pair never ran.  Never hang the GPU: count it in the time-out word, make the bank say
+          atomicAdd(b.ovf + 1, 1);                                          // "do not trust me" and leave the counters alone; the
+          atomicOr(b.ovf, kBankTimeout);                                    // launcher clears the control block before every read)
+        } else {
+          __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean counter for the next read
         }
       }
       __syncthreads();                                                              // E2: all partials of the pair are in memory
     } else {
       __syncthreads();                                                              // (Msh / Lsh visible)
     }
-    // ---- merge (last arriver; or the only segment of the pair).  The others' partials were stored write-through and are
+    // ---- merge (the pair's one aligned block; or the only segment of the pair).  The others' partials were stored write-through and are
     //      read with sc1 loads (L2-coherent at agent scope: no acquire fence, no L1 invalidate needed).
     //      Consumers request the first foreign slot's fragments NOW, before the weights exist.
     int s_first = sself == 0 ? 1 : 0;                      // first foreign slot (if any)
@@ -1709,6 +1921,10 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
       if (c != c0) __syncthreads();   // the previous chunk's LDS (tile prefix, K ring, P, alpha, epilogue scratch) is free
       compute(c);
     }
+    // [r6] the pairs this workgroup holds a segment of, now that its walks are over (the other workgroups of a pair are at most a
+    // few microseconds behind: the chunks are equalised)
+    __syncthreads();
+    for (int c = c0; c < nchunks; c += G) merge_chunk(c);
   }
 
   // =========================================== static part: drain the queue ===========================================

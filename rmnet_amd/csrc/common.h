@@ -167,7 +167,7 @@ struct BankView {
   int32_t* ovf;    // control block (256 B): [0] number of 16-byte groups written (or query elements read) so far that held an element
                    // outside fp16's window, plus the sticky error bits 1 << 30 (slot / frame count out of range) and 1 << 29 (a merge
                    // timed out); [1] merges that timed out; [2] largest soft-max reference of any read so far (float bits, log2 domain, >= 0); [16] the read kernel's static work queue (next item).  Bytes 64.. (queue words, arrival counters) are cleared by the launcher before every read
-  int32_t* cnt;    // [no][nqt_max][2] (arrived, done) counters of the partials of an (object, query tile) pair
+  int32_t* cnt;    // [no][nqt_max][2] (merged, published) counters of the partials of an (object, query tile) pair
                    // (all queue words and counters are zero between reads)
   int no, Tcap, h, w, hw, hwp;
 };
@@ -306,6 +306,35 @@ __host__ __device__ inline int bank_round_chunk_len(int njt, int ps, int P, int 
   int c = plan_div(njt + nb - 1, nb);
   c = plan_div(c + cq - 1, cq) * cq;                                // (fp16 modes: a step is two tiles)
   return c > 0 ? c : 1;
+}
+
+// [r6] CHOICE OF THE PLAN when the launch's pairs fit its workgroups (P <= G).  Candidates, priced in tiles of one workgroup:
+//   * the plain plan (aligned blocks of C tiles + remainder chunks that cross pair boundaries) at the smallest chunk length C0 whose
+//     chunks fit the workgroups: the even cut;
+//   * EQUALISED column blocks at the smallest chunk length c1 whose chunks fit (every object gets ceil(njt / c1) blocks of equal
+//     length: no remainder chunks, every chunk one segment).  Taken when c1 is within 8 % (split: 4 %) of C0 -- the rule of rounds
+//     3-5 -- and ALSO when it cuts nothing (c1 = the longest object: whole pairs, no partials, no merge) and its cost c1 + half a
+//     segment is within 1.15x (fp16 walks) / 1.0x (split) of the plain plan's C0 + a segment.  Measured (cold caches, one box,
+//     tools/plan_ab.sh): 16 clips with boxes of 90-140 tiles, fp16: whole pairs (c1 = 150) 137.7 us against 172.9 us for the plain
+//     plan at C0 = 134 -- its multi-segment remainder chunks cost more than their model; 12 clips (C0 = 100): 131.8 against
+//     115.2 us, the plain plan stays (12 clips with equal boxes of 120 tiles: 114.5 against 108.8 us at C0 = 94); split, 16 clips: 289.6
+//     against 264.6 us at C0 = 118, the plain plan stays.
+//   * NOT taken: equalised blocks in TWO rounds (a workgroup runs chunk c and chunk c + G): 12 clips 105.6 / 128 us warm / cold
+//     against 97 / 115 us for the plain plan -- the second chunk's start-up and publish cost what the finer cut saves.
+__host__ __device__ inline int bank_eq_chunk_len(int njt_max, int nb, int cq, int cmin) {
+  int c = plan_div(njt_max + nb - 1, nb);
+  c = plan_div(c + cq - 1, cq) * cq;
+  return c > cmin ? c : cmin;
+}
+__host__ __device__ inline int bank_eq_count(int nqt, int njt, int c) { return njt > 0 ? nqt * plan_div(njt + c - 1, c) : 0; }
+struct BankPlanPick { int blocks, C; };
+// c1: chunk length of the one-round equalised plan (0: none); uncut: it leaves every pair whole; C0: the plain plan's (0: none)
+__host__ __device__ inline BankPlanPick bank_plan_pick(int c1, bool uncut, int C0, int sc, int kTerms) {
+  if (!C0) return BankPlanPick{c1 ? 2 : 0, c1};
+  if (!c1) return BankPlanPick{0, C0};
+  if (25 * c1 <= (kTerms != 3 ? 27 : 26) * C0) return BankPlanPick{2, c1};
+  if (uncut && 40 * (c1 + sc / 2) <= (kTerms != 3 ? 46 : 40) * (C0 + sc)) return BankPlanPick{2, c1};
+  return BankPlanPick{0, C0};
 }
 
 // Smallest chunk length a launch may use: a chunk must amortise its prologue and 128 KB partial

@@ -126,7 +126,7 @@ void check_object(int nqt, int njt, int C, int sc, int own) {
   }
 }
 
-// bank.hip, the plan: smallest chunk length whose chunks fit `target` workgroups, then "own column blocks" if they fit too
+// bank.hip, the plan
 void check_launch(const std::vector<int>& nqt, const std::vector<int>& njt, int target, int sc, int cq) {
   long long W = 0;
   int njt_max = 0;
@@ -164,21 +164,42 @@ void check_launch(const std::vector<int>& nqt, const std::vector<int>& njt, int 
       return;
     }
   }
-  int C0 = std::max((int)((W + target - 1) / target), bank_chunk_min(njt_max));
-  C0 = (C0 + cq - 1) / cq * cq;
-  int it = 0;
-  for (; it < 1024 && total(C0, 0) > target; ++it) C0 += (1 + (C0 >> 5) + cq - 1) / cq * cq;
-  CHECK(it < 1024, "the search for C did not end (W %lld target %d)", W, target);
-  CHECK(total(C0, 0) <= target, "more chunks (%d) than workgroups (%d)", total(C0, 0), target);
-  // the equalised plan at C0 or one of the next two candidates (the split mode: next one), else own blocks, else plain -- bank.hip
-  int blocks = 0;
-  {
-    const int c1 = C0 + (1 + (C0 >> 5) + cq - 1) / cq * cq, c2 = c1 + (1 + (c1 >> 5) + cq - 1) / cq * cq;
-    const int ceq = total(C0, 2) <= target ? C0 : total(c1, 2) <= target ? c1 : (total(c2, 2) <= target && sc != kSegCost) ? c2 : 0;
-    if (ceq) { C0 = ceq; blocks = 2; }
+  // [r6] pairs fit the workgroups: bank_plan_pick() over the equalised plan and the plain plan, priced as bank.hip's
+  // planning wave prices them (lane i = candidate i)
+  const int cmin = (bank_chunk_min(njt_max) + cq - 1) / cq * cq;
+  int Clo = std::max((int)((W + target - 1) / target), cmin);
+  Clo = (Clo + cq - 1) / cq * cq;
+  const int Chi = std::max((njt_max + cq - 1) / cq * cq, Clo);
+  const int step = (std::max((Chi - Clo + 62) / 63, 1) + cq - 1) / cq * cq;
+  int l1 = -1, ce[64], cp[64], lp = -1;
+  for (int i = 0; i < 64; ++i) {
+    ce[i] = bank_eq_chunk_len(njt_max, i + 1, cq, cmin);
+    cp[i] = Clo + i * step;
+    int me = 0;
+    for (size_t o = 0; o < nqt.size(); ++o) me += bank_eq_count(nqt[o], njt[o], ce[i]);
+    CHECK(me == total(ce[i], 2), "bank_eq_count and bank_chunks(.., 2) disagree at c %d: %d vs %d", ce[i], me, total(ce[i], 2));
+    if (me <= target) l1 = i;
+    if (lp < 0 && total(cp[i], 0) <= target) lp = i;
   }
+  const int c1 = l1 >= 0 ? ce[l1] : 0;
+  CHECK(c1 > 0, "no one-round equalised plan although the pairs fit the workgroups (target %d)", target);
+  const BankPlanPick pk = bank_plan_pick(c1, c1 >= njt_max, lp >= 0 ? cp[lp] : 0, sc, sc == kSegCost ? 3 : 1);
+  const int C0 = pk.C > 0 ? pk.C : Chi;
+  int blocks = pk.blocks;
   if (!blocks && total(C0, 1) <= target) blocks = 1;
-  CHECK(total(C0, blocks) <= target, "plan %d: more chunks (%d) than workgroups (%d)", blocks, total(C0, blocks), target);
+  CHECK(total(C0, blocks) <= target, "plan %d at C %d: more chunks (%d) than workgroups (%d)", blocks, C0, total(C0, blocks), target);
+  {   // partial slots of the launch fit the workspace of a launch group (common.h: bank_group_slot0)
+    long long slots = 0;
+    int nq_max = 0;
+    for (size_t o = 0; o < nqt.size(); ++o) {
+      const BankChunks bc = bank_chunks(nqt[o], njt[o], C0, sc, blocks);
+      slots += bc.nch + (bc.R > 0 ? nqt[o] : 0);
+      nq_max = std::max(nq_max, nqt[o]);
+    }
+    CHECK(slots <= (long long)target + (long long)nqt.size() * nq_max, "%lld partial slots exceed the workspace of a launch group", slots);
+  }
+  if (blocks == 2)   // an equalised plan never cuts a pair into more partials than the merge holds
+    for (size_t o = 0; o < nqt.size(); ++o) CHECK(bank_chunks(nqt[o], njt[o], C0, sc, 2).nfull <= kSplitMax, "object %zu cut %d-fold", o, bank_chunks(nqt[o], njt[o], C0, sc, 2).nfull);
   for (size_t o = 0; o < nqt.size(); ++o) check_object(nqt[o], njt[o], C0, sc, blocks);
 }
 

@@ -10,7 +10,7 @@ from rmnet_amd import ops
 from bench import HipEvents
 no, qh, qw, mh, mw = [int(x) for x in sys.argv[1:6]]
 T = int(sys.argv[6]) if len(sys.argv) > 6 else 5
-h, w = 30, 54
+h, w = (qh, qw) if qh > 30 else (30, 54)   # (a box larger than the 480p grid: that grid, dense)
 dev = torch.device('cuda', 0)
 g = torch.Generator().manual_seed(0)
 mk = (torch.randn(no, 128, T, h, w, generator=g) * 0.6).to(dev)
@@ -57,5 +57,15 @@ bm = [ev.elapsed_ms(ev.ev[3 * i], ev.ev[3 * i + 1]) * 1e3 - floor for i in range
 bc = [ev.elapsed_ms(ev.ev[3 * i + 1], ev.ev[3 * i + 2]) * 1e3 - floor for i in range(reps)]
 nqt = (qh * qw + 1 + 63) // 64
 njt = T * ((mh * mw + 31) // 32)
+# the plan bk_main left in the workspace (common.h: kPlanInts = 12 ints per object: ..., [9] chunk length, [10] chunks of the launch)
+from rmnet_amd import _lib
+lib = _lib.load()
+ws = torch.zeros(int(lib.rmnet_bank_read_workspace_bytes_for(no, h, w, T)), dtype=torch.uint8, device=dev)
+bank.read(T, qk, qv, qr, ws=ws)
+torch.cuda.synchronize()
+a256 = lambda x: (x + 255) & ~255
+tsl = 256 + no * ((h * w + 63) // 64)
+pl = ws[a256(tsl * 512 * 64 * 4) + a256(tsl * 2 * 64 * 4):][:no * 48].view(torch.int32).view(no, 12).cpu().numpy()
+print('plan: chunks %d | per object (nqt, njt, chunk length): %s' % (pl[0, 10], ' '.join('%d,%d,%d' % (r[1], r[2], r[9]) for r in pl[:6])))
 print('no=%d nqt=%d njt=%d pairs*tiles=%d | bk_main avg %.2f min %.2f us | combine avg %.2f min %.2f us (event floor %.2f us subtracted)'
       % (no, nqt, njt, no * nqt * njt, np.mean(bm), np.min(bm), np.mean(bc), np.min(bc), floor))

@@ -22,15 +22,15 @@ run() { log "$*"; ( "$@" ) >> $out/log.txt 2>&1; echo "rc=$?" | tee -a $out/log.
 
 case $recipe in
 walk_ab)
-  for mode in f16 qx; do
+  for mode in ${STRESS_MODES:-f16 qx}; do
     run env RMNET_BANK_PRECISION=$mode timeout 600 python tests/stress_race.py 40
     run env RMNET_BANK_PRECISION=$mode timeout 300 python tests/stress_bank.py
   done
   run timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -m gpu -k "f16_mode_vs_oracle or qx_mode_vs_oracle or peaked or qx_mode_on_large or strides_partial or dropin_memory_read_f16 or long_memory or one_launch_limit or repeatable"
   libs="rmnet_amd/librmnet_hip.so $(ls build/variants/lib_*.so 2>/dev/null)"
-  for mode in f16 qx; do
+  for mode in ${MODES:-f16 qx}; do
     for lib in $libs; do
-      for shape in "16 0 0 0 0 5" "8 0 0 0 0 5" "16 21 36 21 36 5" "1 30 54 30 54 5" "20 0 0 0 0 5" "5 0 0 0 0 5"; do
+      for shape in "16 0 0 0 0 5" "8 0 0 0 0 5" "16 21 36 21 36 5" "1 30 54 30 54 5" "20 0 0 0 0 5" "5 0 0 0 0 5" ${MORE_SHAPES:+"1 0 0 0 0 5" "4 0 0 0 0 5" "12 0 0 0 0 5" "3 45 80 45 80 20"}; do
         log "$mode $lib chunk_bench $shape"
         RMNET_HIP_LIB=$PWD/$lib RMNET_BANK_PRECISION=$mode timeout 300 python tools/chunk_bench.py $shape 2>&1 | tail -1 | tee -a $out/log.txt
         log "$mode $lib FLUSH=512 chunk_bench $shape"
