@@ -1484,14 +1484,14 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     }
     // [r6] The plan (common.h: bank_plan_pick).  64 candidates of each kind are priced AT ONCE, one per lane, in one loop over the
     // objects (the search sits on the critical path of every workgroup: until round 5 it walked the candidates four at a time with
-    // wave reductions -- 5-6 rounds at the bench launch): lane i prices the equalised plan with i + 1 column blocks of the
-    // longest object and the plain plan at chunk length Clo + i * step (from the even cut to the longest object).
+    // wave reductions -- 5-6 rounds at the bench launch): lane i prices the i-th equalised candidate (common.h:
+    // bank_eq_candidate) and -- if needed -- the plain plan at chunk length Clo + i * step (from the even cut to the longest object).
     constexpr int kSC = seg_cost_of(kTerms);
     constexpr int kCq = kTerms != 3 ? 2 : 1;              // (fp16 modes: a step is two tiles, an odd chunk wastes half of one)
     const int cmin = (bank_chunk_min(njt_max) + kCq - 1) / kCq * kCq;
-    const int ce = bank_eq_chunk_len(njt_max, tid + 1, kCq, cmin);
     int Clo = max(W < (1 << 22) ? plan_div(W + target - 1, target) : (W + target - 1) / target, cmin);
     Clo = (Clo + kCq - 1) / kCq * kCq;
+    const int ce = bank_eq_candidate(tid, njt_max, Clo, kCq, cmin);
     const int Chi = max((njt_max + kCq - 1) / kCq * kCq, Clo);
     const int step = (max(plan_div(Chi - Clo + 62, 63), 1) + kCq - 1) / kCq * kCq;
     const int cp = Clo + tid * step;
@@ -1499,16 +1499,22 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     const int P = wave_sum_fast(nqe);
     int C0 = Clo, blocks = 0;
     if (P <= target) {
-      int me = 0, mp = 0;
-      for (int o = 0; o < ng; ++o) {    // (lane o holds object o's tile counts: a readlane per object, no LDS round trip)
-        const int nq = __builtin_amdgcn_readlane(nqt, o), nj = __builtin_amdgcn_readlane(njt, o);
-        me += bank_eq_count(nq, nj, ce);
-        mp += bank_chunks(nq, nj, cp, kSC, 0).nch;
+      int me = 0;
+      for (int o = 0; o < ng; ++o)      // (lane o holds object o's tile counts: a readlane per object, no LDS round trip)
+        me += bank_eq_count(__builtin_amdgcn_readlane(nqt, o), __builtin_amdgcn_readlane(njt, o), ce);
+      const int c1n = wave_max_fast(me <= target ? -ce : -0x3fffffff);          // smallest chunk length whose equalised chunks fit
+      const int c1 = c1n > -0x3fffffff ? -c1n : 0;
+      const int cw = __builtin_amdgcn_readlane(ce, 0);                          // whole pairs (they fit: P <= target)
+      // The plain plan's chunk length C0 is >= the even cut Clo: when the equalised plan wins against Clo it wins against C0 and the
+      // plain candidates (three divisions per object and lane) are not priced at all -- the bench launch's case
+      BankPlanPick pk = bank_plan_pick(c1, cw, Clo, kSC, kTerms);
+      if (pk.blocks == 0) {
+        int mp = 0;
+        for (int o = 0; o < ng; ++o)
+          mp += bank_chunks(__builtin_amdgcn_readlane(nqt, o), __builtin_amdgcn_readlane(njt, o), cp, kSC, 0).nch;
+        const unsigned long long fp = __ballot(mp <= target);
+        pk = bank_plan_pick(c1, cw, fp ? __builtin_amdgcn_readlane(cp, __builtin_ctzll(fp)) : 0, kSC, kTerms);
       }
-      const unsigned long long f1 = __ballot(me <= target), fp = __ballot(mp <= target);
-      const int l1 = f1 ? 63 - __builtin_clzll(f1) : -1;
-      const int c1 = l1 >= 0 ? __builtin_amdgcn_readlane(ce, l1) : 0;
-      const BankPlanPick pk = bank_plan_pick(c1, c1 >= njt_max, fp ? __builtin_amdgcn_readlane(cp, __builtin_ctzll(fp)) : 0, kSC, kTerms);
       C0 = pk.C > 0 ? pk.C : Chi;
       blocks = pk.blocks;
       if (!blocks && wave_sum_fast(bank_chunks(nqt, njt, C0, kSC, 1).nch) <= target) blocks = 1;   // short objects as blocks of their own (common.h)
@@ -1568,7 +1574,8 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     if (cl < m.nqt * bc.nfull) {
       const int blk = plan_div(cl, m.nqt);
       m.qt = cl - blk * m.nqt; m.sself = blk;
-      if (bc.nfull >= 2) merge_pair<kTerms>(m, Kl_, Pl_, &sgave);    // (exactly one aligned block: merged by it in place, run_segment)
+      // (exactly one aligned block, or two segments in all: merged in place by the pair's last arriver, run_segment)
+      if (bc.nfull >= 2 && pair_slots(m.slot_obj, m.nqt, bc, m.qt).count > 2) merge_pair<kTerms>(m, Kl_, Pl_, &sgave);
       return;
     }
     const int cr = cl - m.nqt * bc.nfull;
@@ -1577,7 +1584,7 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     for (int qt = plan_div(u0, span); qt < m.nqt && qt * span < u1; ++qt) {
       if (min(u1 - qt * span, bc.R) <= max(u0 - qt * span, 0)) continue;
       m.qt = qt; m.sself = bc.nfull + cr - plan_div(qt * span, m.C);
-      if (pair_slots(m.slot_obj, m.nqt, bc, qt).count > 1) merge_pair<kTerms>(m, Kl_, Pl_, &sgave);
+      if (pair_slots(m.slot_obj, m.nqt, bc, qt).count > 2) merge_pair<kTerms>(m, Kl_, Pl_, &sgave);
     }
   };
 
@@ -1682,12 +1689,22 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
     float* Lsh = Al + kQT;
     const int dt0 = kCDT * (wave - kProducers);           // (consumers) first channel tile of this wave
     // [r6] Who merges a pair of several segments:
-    //   * a pair with exactly ONE aligned column block (the plain plan: one block + remainder chunks): that block's workgroup, HERE, with
-    //     its own partial in registers -- it waits until the remainder segments are published (their workgroups only publish and
-    //     go on: the wait cannot deadlock, whatever is resident) and adds them slot by slot;
-    //   * every other pair (equalised blocks, rounds, remainder-only pairs): all its workgroups (or its aligned ones) together, after
-    //     their walks (merge_pair): this segment publishes and goes on.
-    const bool owner_here = nsp > 1 && ps.na == 1 && sself == 0;
+    //   * a pair with exactly ONE aligned column block (the plain plan: one block + remainder chunks), and a pair of TWO segments:
+    //     its LAST ARRIVER (a ticket on the pair's first counter), HERE, with its own partial in registers -- the others hold a
+    //     ticket, i.e. they have left their walks and only store: the wait for their publications cannot deadlock, whatever is
+    //     resident -- and adds them slot by slot (two segments: one trip for the other's 128 KB; measured: 1.6 us less than
+    //     publishing both and merging half each; a FIXED owner instead of the last arriver waits for the later one half of the
+    //     time: +4 % at 8 / 12 object-frames);
+    //   * every other pair (three or more equalised blocks, rounds, remainder-only pairs): all its workgroups (or its aligned ones)
+    //     together, after their walks (merge_pair): this segment publishes and goes on.
+    if (producer && g == 0) { Msh[wave * 16 + l15] = m_seg; Lsh[wave * 16 + l15] = l_seg; }
+    bool owner_here = false;
+    int* const pair_cnt = b.cnt + 2 * ((size_t)wk.o * bank_nqt_max(hw) + wk.qt);
+    if (nsp > 1 && (ps.na == 1 || nsp == 2)) {
+      if (tid == 0) sflag = __hip_atomic_fetch_add(pair_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();                                                              // E1: the ticket (and Msh / Lsh)
+      owner_here = sld(sflag) == nsp - 1;
+    }
     if (nsp > 1 && !owner_here) {
       // ---- publish with write-through (sc1) stores, drained by every storing wave, THEN count it
       //      (cdna_hip_programming.md section 6 Guideline 16, recipe R1 in its counter form)
@@ -1706,13 +1723,11 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                                                            // every wave's stores have landed
-      if (tid == 0)
-        __hip_atomic_fetch_add(b.cnt + 2 * ((size_t)wk.o * bank_nqt_max(hw) + wk.qt) + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) __hip_atomic_fetch_add(pair_cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
-    if (producer && g == 0) { Msh[wave * 16 + l15] = m_seg; Lsh[wave * 16 + l15] = l_seg; }
     if (owner_here) {
-      int* done = b.cnt + 2 * ((size_t)wk.o * bank_nqt_max(hw) + wk.qt) + 1;
+      int* done = pair_cnt + 1;
       if (tid == 0) {
         int polls = 0;
         bool gave_up = false;
@@ -1725,14 +1740,15 @@ __global__ __launch_bounds__(kRThreads, 1) void bk_main(const BArgs a) {
           atomicAdd(b.ovf + 1, 1);                                          // "do not trust me" and leave the counters alone; the
           atomicOr(b.ovf, kBankTimeout);                                    // launcher clears the control block before every read)
         } else {
-          __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean counter for the next read
+          __hip_atomic_store(pair_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean counters for the next read
+          __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       __syncthreads();                                                              // E2: all partials of the pair are in memory
     } else {
       __syncthreads();                                                              // (Msh / Lsh visible)
     }
-    // ---- merge (the pair's one aligned block; or the only segment of the pair).  The others' partials were stored write-through and are
+    // ---- merge (the last arriver of an in-place pair; or the only segment of the pair).  The others' partials were stored write-through and are
     //      read with sc1 loads (L2-coherent at agent scope: no acquire fence, no L1 invalidate needed).
     //      Consumers request the first foreign slot's fragments NOW, before the weights exist.
     int s_first = sself == 0 ? 1 : 0;                      // first foreign slot (if any)

@@ -312,10 +312,11 @@ __host__ __device__ inline int bank_round_chunk_len(int njt, int ps, int P, int 
 //   * the plain plan (aligned blocks of C tiles + remainder chunks that cross pair boundaries) at the smallest chunk length C0 whose
 //     chunks fit the workgroups: the even cut;
 //   * EQUALISED column blocks at the smallest chunk length c1 whose chunks fit (every object gets ceil(njt / c1) blocks of equal
-//     length: no remainder chunks, every chunk one segment).  Taken when c1 is within 8 % (split: 4 %) of C0 -- the rule of rounds
-//     3-5 -- and ALSO when it cuts nothing (c1 = the longest object: whole pairs, no partials, no merge) and its cost c1 + half a
+//     length: no remainder chunks, every chunk one segment): taken when c1 is within 8 % (split: 4 %) of C0 -- the rule of rounds 3-5
+//     (the bench launch: clips of 100-140 tiles at c1 = 122: the longest few cut in two, merged in place);
+//   * WHOLE pairs (chunk length cw = the longest object: no partials, no merge) when its cost cw + half a
 //     segment is within 1.15x (fp16 walks) / 1.0x (split) of the plain plan's C0 + a segment.  Measured (cold caches, one box,
-//     tools/plan_ab.sh): 16 clips with boxes of 90-140 tiles, fp16: whole pairs (c1 = 150) 137.7 us against 172.9 us for the plain
+//     tools/plan_ab.sh): 16 clips with boxes of 90-140 tiles, fp16: whole pairs (cw = 150) 137.7 us against 172.9 us for the plain
 //     plan at C0 = 134 -- its multi-segment remainder chunks cost more than their model; 12 clips (C0 = 100): 131.8 against
 //     115.2 us, the plain plan stays (12 clips with equal boxes of 120 tiles: 114.5 against 108.8 us at C0 = 94); split, 16 clips: 289.6
 //     against 264.6 us at C0 = 118, the plain plan stays.
@@ -328,12 +329,22 @@ __host__ __device__ inline int bank_eq_chunk_len(int njt_max, int nb, int cq, in
 }
 __host__ __device__ inline int bank_eq_count(int nqt, int njt, int c) { return njt > 0 ? nqt * plan_div(njt + c - 1, c) : 0; }
 struct BankPlanPick { int blocks, C; };
-// c1: chunk length of the one-round equalised plan (0: none); uncut: it leaves every pair whole; C0: the plain plan's (0: none)
-__host__ __device__ inline BankPlanPick bank_plan_pick(int c1, bool uncut, int C0, int sc, int kTerms) {
-  if (!C0) return BankPlanPick{c1 ? 2 : 0, c1};
-  if (!c1) return BankPlanPick{0, C0};
-  if (25 * c1 <= (kTerms != 3 ? 27 : 26) * C0) return BankPlanPick{2, c1};
-  if (uncut && 40 * (c1 + sc / 2) <= (kTerms != 3 ? 46 : 40) * (C0 + sc)) return BankPlanPick{2, c1};
+// The equalised candidates of a launch, 64 of them (one per lane of bank.hip's planning wave): i < kBankEqByBlocks: the longest object
+// in i + 1 column blocks; the others: chunk lengths from the even cut Clo upwards in 16 steps over a quarter of it (where the 8 % rule can still hold)
+constexpr int kBankEqByBlocks = 48;
+__host__ __device__ inline int bank_eq_candidate(int i, int njt_max, int Clo, int cq, int cmin) {
+  if (i < kBankEqByBlocks) return bank_eq_chunk_len(njt_max, i + 1, cq, cmin);
+  int st = plan_div(Clo + 63, 64);
+  st = plan_div(st + cq - 1, cq) * cq;
+  const int c = Clo + (i - kBankEqByBlocks) * st;
+  return c > cmin ? c : cmin;
+}
+// c1: the smallest chunk length whose equalised chunks fit the workgroups (0: none); cw: the chunk length that leaves every pair whole
+// (0: they do not fit); C0: the plain plan's (0: none)
+__host__ __device__ inline BankPlanPick bank_plan_pick(int c1, int cw, int C0, int sc, int kTerms) {
+  if (!C0) return BankPlanPick{(c1 || cw) ? 2 : 0, c1 ? c1 : cw};
+  if (c1 && 25 * c1 <= (kTerms != 3 ? 27 : 26) * C0) return BankPlanPick{2, c1};
+  if (cw && 40 * (cw + sc / 2) <= (kTerms != 3 ? 46 : 40) * (C0 + sc)) return BankPlanPick{2, cw};
   return BankPlanPick{0, C0};
 }
 

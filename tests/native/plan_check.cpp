@@ -171,19 +171,21 @@ void check_launch(const std::vector<int>& nqt, const std::vector<int>& njt, int 
   Clo = (Clo + cq - 1) / cq * cq;
   const int Chi = std::max((njt_max + cq - 1) / cq * cq, Clo);
   const int step = (std::max((Chi - Clo + 62) / 63, 1) + cq - 1) / cq * cq;
-  int l1 = -1, ce[64], cp[64], lp = -1;
+  int c1 = 0, ce[64], cp[64], lp = -1;
   for (int i = 0; i < 64; ++i) {
-    ce[i] = bank_eq_chunk_len(njt_max, i + 1, cq, cmin);
+    ce[i] = bank_eq_candidate(i, njt_max, Clo, cq, cmin);
     cp[i] = Clo + i * step;
     int me = 0;
     for (size_t o = 0; o < nqt.size(); ++o) me += bank_eq_count(nqt[o], njt[o], ce[i]);
     CHECK(me == total(ce[i], 2), "bank_eq_count and bank_chunks(.., 2) disagree at c %d: %d vs %d", ce[i], me, total(ce[i], 2));
-    if (me <= target) l1 = i;
+    if (me <= target && (c1 == 0 || ce[i] < c1)) c1 = ce[i];
     if (lp < 0 && total(cp[i], 0) <= target) lp = i;
   }
-  const int c1 = l1 >= 0 ? ce[l1] : 0;
+  const int cw = ce[0];
+  CHECK(total(cw, 2) <= target, "whole pairs (%d chunks) do not fit %d workgroups although P <= target", total(cw, 2), target);
   CHECK(c1 > 0, "no one-round equalised plan although the pairs fit the workgroups (target %d)", target);
-  const BankPlanPick pk = bank_plan_pick(c1, c1 >= njt_max, lp >= 0 ? cp[lp] : 0, sc, sc == kSegCost ? 3 : 1);
+  BankPlanPick pk = bank_plan_pick(c1, cw, Clo, sc, sc == kSegCost ? 3 : 1);   // (against the even cut first: bank.hip)
+  if (pk.blocks == 0) pk = bank_plan_pick(c1, cw, lp >= 0 ? cp[lp] : 0, sc, sc == kSegCost ? 3 : 1);
   const int C0 = pk.C > 0 ? pk.C : Chi;
   int blocks = pk.blocks;
   if (!blocks && total(C0, 1) <= target) blocks = 1;

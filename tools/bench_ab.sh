@@ -2,7 +2,7 @@
 # The default bench line (launch sizes, modes, single stream) with the tree's library and with build/variants/lib_old.so, interleaved:
 #     gpurun -- 'tools/gpurun_call.sh <tag> cmd bash tools/bench_ab.sh <tag>'
 out=gpurun_out/$1
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
   for lib in rmnet_amd/librmnet_hip.so build/variants/lib_old.so; do
     [ -f $lib ] || continue
     n=$(basename $lib .so)_$rep

@@ -1,5 +1,6 @@
 # -*- coding: utf-8 -*-
-"""Shader clock and static-queue accounting of bk_main (needs a library built with -DBK_CLK=1): per workgroup,
+"""Time line and static-queue accounting of bk_main (needs the stamped library: `PATCH=tools/patches/clk_stamps_r6.patch tools/build_variant.sh clk`,
+run with RMNET_HIP_LIB=build/variants/lib_clk.so; FLUSH=<MB> streams that much between two reads = the frame loop's cold caches): per workgroup,
 elapsed shader cycles (s_memtime) vs elapsed constant-rate ticks (s_memrealtime, 100 MHz) of its compute part, the
 number of static-queue tickets it served and when it left the kernel.
     python tools/bk_clk.py <no> <q_h> <q_w> <m_h> <m_w> [T]"""
@@ -32,14 +33,19 @@ for t in range(T):
 lib = _lib.load()
 nb = lib.rmnet_bank_read_workspace_bytes(no, h, w)
 ws = torch.zeros(nb, dtype=torch.uint8, device=dev)
+flush = int(os.environ.get('FLUSH', '0'))
+if flush:
+    fa = torch.empty(flush * 262144, device=dev); fb = torch.ones(flush * 262144, device=dev)
 for _ in range(20):
+    if flush:
+        fa.copy_(fb); fa.mul_(1.0001)
     bank.read(T, qk, qv, qr, ws=ws)
 torch.cuda.synchronize()
 # the stamps start 64 bytes after the plan records (which end somewhere inside the last 256-byte pad)
 plan_end = (no * 12 * 4)
-raw = ws[nb - 16384 - ((plan_end + 255) // 256 * 256) + plan_end + 64:][:256 * 64].view(torch.int64).cpu().numpy().reshape(-1, 8)
-comp = raw[(raw[:, 1] > 0) & (raw[:, 0] > 0)]
-ghz = comp[:, 0] / (comp[:, 1] * 10.0)   # cycles per ns (100 MHz real-time ticks = 10 ns each)
+raw = ws[nb - 16384 - 256 - ((plan_end + 255) // 256 * 256) + plan_end + 64:][:256 * 64].view(torch.int64).cpu().numpy().reshape(-1, 8)
+comp = raw[raw[:, 1] > 0]
+ghz = np.zeros(len(comp))
 print('no=%d: %d workgroups stamped; compute part: shader cycles %.0f..%.0f, real us %.1f..%.1f, clock GHz mean %.3f min %.3f max %.3f'
       % (no, len(comp), comp[:, 0].min(), comp[:, 0].max(), comp[:, 1].min() / 100.0, comp[:, 1].max() / 100.0, ghz.mean(), ghz.min(), ghz.max()))
 tick, left = raw[:, 2], raw[:, 3] / 100.0
@@ -52,5 +58,6 @@ print('static queue: %d tickets served in all; set-aside workgroups (%d): %s tic
 c = raw[(raw[:, 1] > 0)][~early]
 us = lambda col: c[:, col] / 100.0
 print('compute workgroups, microseconds since kernel entry (median [min..max]): plan done %.1f [%.1f..%.1f]; first tile walk starts %.1f [%.1f..%.1f]; '
-      'last tile walk over %.1f [%.1f..%.1f]; epilogue (publish / merge / output) over %.1f [%.1f..%.1f]; left the kernel %.1f [%.1f..%.1f]'
-      % tuple(x for col in (4, 5, 6, 1, 3) for x in (np.median(us(col)), us(col).min(), us(col).max())))
+      'last tile walk over %.1f [%.1f..%.1f]; epilogue (publish / in-place merge / output) over %.1f [%.1f..%.1f]; deferred merges over %.1f [%.1f..%.1f]; '
+      'left the kernel (static queue drained) %.1f [%.1f..%.1f]'
+      % tuple(x for col in (4, 5, 6, 1, 7, 3) for x in (np.median(us(col)), us(col).min(), us(col).max())))
