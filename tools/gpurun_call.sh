@@ -10,6 +10,7 @@
 #   prof  [args]   rocprofv3 --kernel-trace --stats of bench.py [args] -> kernel table (tools/rocprof_summary.py)
 #   conv_layout    the convolution half of 8f-3: fused / unfused / folded / channels_last frames/s + the NHWC run's kernel table
 #   record         the round's record: suite + smoke, default bench line, rocprofv3 table, PMC traffic x 3, in-loop counters, stress
+#   record_lite    the record without the PMC traffic / counter passes
 #   cmd   <...>    any command line
 set -u
 cd "$(dirname "$0")/.."
@@ -84,6 +85,16 @@ record)
   mkdir -p build/variants; cp rmnet_amd/librmnet_hip.so build/variants/lib_main.so
   VARIANTS="main" bash tools/pmc_loop.sh $tag/counters > /dev/null 2>&1; cp gpurun_out/$tag/counters/summary.txt $out/counters.txt
   for mode in f16 qx split; do RMNET_BANK_PRECISION=$mode timeout 900 python tests/stress_race.py 150 2>&1 | tail -1; done | tee $out/stress.txt
+  ;;
+record_lite)
+  # the record without the PMC passes (when GPU minutes are short): suite + smoke, default bench line, rocprofv3 table, drop-in rows, stress
+  run timeout 1400 python -m pytest tests -q -m gpu --durations=15
+  run python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"
+  log "python bench.py"
+  timeout 900 python bench.py > $out/bench_line.json 2> $out/bench.err; python tools/show_line.py $out/bench_line.json | tee -a $out/log.txt
+  bash tools/profile_round.sh > $out/profile_round.txt 2>&1; cp gpurun_out/prof/timed_region.md $out/timed_region.md; cp gpurun_out/prof/bench_line.json $out/bench_line_under_rocprof.json
+  for flags in 0 4 8; do echo "== drop-in flags $flags"; FLAGS=$flags N=200 timeout 300 python tools/dropin_trace.py 2>&1 | tail -1; done | tee $out/dropin.txt
+  for mode in f16 qx split; do RMNET_BANK_PRECISION=$mode timeout 400 python tests/stress_race.py ${STRESS_N:-60} 2>&1 | tail -1; done | tee $out/stress.txt
   ;;
 cmd)
   run "$@"

@@ -118,6 +118,7 @@ def main():
     ap.add_argument('--scales', default='1,2,4,8')
     ap.add_argument('--threads', type=int, default=8)
     ap.add_argument('--out', default='')
+    ap.add_argument('--modes', default='f16,qx,mixed', help="CPU emulation: arithmetics of live_fixture.rounded_reader, e.g. f16,qx,mixed,P,V")
     ap.add_argument('--deltas', default='', help='JSON {fixture: {scale: delta}} from an earlier run: skip the bisection')
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
@@ -163,7 +164,7 @@ def main():
                     ious = [lf.label_iou(est, ref, k) for k in range(1, n_obj + 1)]
                     emit('%s GPU %s | %.5f | %.2e |' % (head, mode, min(ious), lf.logit_gap(lg, ref_l)))
             else:
-                for mode in ('f16', 'qx', 'mixed'):
+                for mode in args.modes.split(','):
                     est, lg = cpu_net(lf.rounded_reader(mode), s, delta)(frames, masks, flows, n_objects, every, return_logits=True)
                     ious = [lf.label_iou(est, ref, k) for k in range(1, n_obj + 1)]
                     emit('%s emulated %s | %.5f | %.2e |' % (head, mode, min(ious), lf.logit_gap(lg, ref_l)))
