@@ -8,4 +8,12 @@ for flags in 0 4 8; do
     FLAGS=$flags N=200 RMNET_HIP_LIB=$PWD/$lib timeout 300 python tools/dropin_trace.py 2>&1 | tail -1
   done
 done
-bash tools/exp_dropin.sh
+# per-kernel rows of one call (rocprofv3 --kernel-trace --stats of tools/dropin_trace.py without its graph section)
+(
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$OLDPWD}
+mkdir -p $R/gpurun_out/dropin
+NOGRAPH=1 timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/dropin/prof -o d -- python $R/tools/dropin_trace.py > $R/gpurun_out/dropin/prof.log 2>&1
+f=$(find $R/gpurun_out/dropin/prof -name '*kernel_stats.csv' | head -1)
+cat $f | head -20
+)
