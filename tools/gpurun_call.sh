@@ -11,6 +11,7 @@
 #   conv_layout    the convolution half of 8f-3: fused / unfused / folded / channels_last frames/s + the NHWC run's kernel table
 #   record         the round's record: suite + smoke, default bench line, rocprofv3 table, PMC traffic x 3, in-loop counters, stress
 #   record_lite    the record without the PMC traffic / counter passes
+#   pmc            the PMC half of the record: HBM traffic x 3 arithmetics, in-loop counters
 #   cmd   <...>    any command line
 set -u
 cd "$(dirname "$0")/.."
@@ -95,6 +96,14 @@ record_lite)
   bash tools/profile_round.sh > $out/profile_round.txt 2>&1; cp gpurun_out/prof/timed_region.md $out/timed_region.md; cp gpurun_out/prof/bench_line.json $out/bench_line_under_rocprof.json
   for flags in 0 4 8; do echo "== drop-in flags $flags"; FLAGS=$flags N=200 timeout 300 python tools/dropin_trace.py 2>&1 | tail -1; done | tee $out/dropin.txt
   for mode in f16 qx split; do RMNET_BANK_PRECISION=$mode timeout 400 python tests/stress_race.py ${STRESS_N:-60} 2>&1 | tail -1; done | tee $out/stress.txt
+  ;;
+pmc)
+  # the PMC half of the record: HBM traffic of bk_main in the three arithmetics (separate --pmc passes, stamped with bench.source_hash()),
+  # then the SQ / TCC counters of bk_main inside the loop
+  for prec in ${PRECS:-f16 qx split}; do PRECISION=$prec bash tools/pmc_traffic.sh > $out/pmc_traffic_$prec.txt 2>&1; tail -2 $out/pmc_traffic_$prec.txt; done
+  cp profiles/bk_main*_hbm_traffic.json $out/
+  mkdir -p build/variants; cp rmnet_amd/librmnet_hip.so build/variants/lib_main.so
+  VARIANTS="main" bash tools/pmc_loop.sh $tag/counters > /dev/null 2>&1; cp gpurun_out/$tag/counters/summary.txt $out/counters.txt; tail -30 $out/counters.txt
   ;;
 cmd)
   run "$@"
