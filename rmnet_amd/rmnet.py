@@ -88,7 +88,11 @@ class RMNet(nn.Module):
         #         key convolutions scaled so that the soft-max is peaked (top-1 mass 0.5: |S| ~ 150) 'f16' AND 'qx' fall to 0.9985-0.9990,
         #         below the bar, while 'split' stays on the exact loop (profiles/r06_iou_temperature.md; tests/test_gpu_parity.py
         #         test_key_temperature_sweep).  No trained checkpoint is reachable offline: the bound is what the sweep supports.
+        #         The decision is STICKY per network: the logit scale is a property of the weights, so once a one-object clip had to be
+        #         re-read, later clips of this network start in 'split' (no clip is processed twice again); ``reset_auto_precision()``
+        #         -- also called when reference weights are loaded -- returns to the optimistic start.
         self.read_precision = ops._loop_precision(read_precision)
+        self._auto_peaked = False
         self.encoder_memory = EncoderMemory()
         self.encoder_query = EncoderQuery()
         self.kv_memory = KeyValue(1024, keydim=128, valdim=512)
@@ -103,7 +107,12 @@ class RMNet(nn.Module):
         """Accepts the reference's checkpoints with or without DataParallel's ``module.`` prefix
         (core/inference.py:43, utils/eval_server.py:92)."""
         clean = {(k[7:] if k.startswith('module.') else k): v for k, v in state_dict.items()}
+        self.reset_auto_precision()          # (new weights, new logit scale)
         return self.load_state_dict(clean, strict=strict)
+
+    def reset_auto_precision(self):
+        """'auto' forgets that a clip of this network measured logits beyond AUTO_LOGIT_BOUND (see __init__)."""
+        self._auto_peaked = False
 
     def fuse_for_inference(self):
         """Fold the eval-mode BatchNorms of both ResNet-50 trunks into their convolutions (in place;
@@ -340,10 +349,10 @@ class RMNet(nn.Module):
 
     def resolve_read_precision(self, n_objects):
         """The arithmetic a clip with ``n_objects`` objects per batch element STARTS in ('auto': see __init__; a one-object clip whose
-        logits turn out large is re-read in 'split' at the end of ``forward``)."""
+        logits turn out large is re-read in 'split' at the end of ``forward``, and one-object clips start in 'split' from then on)."""
         if self.read_precision != 'auto':
             return self.read_precision
-        return 'f16' if all(int(n) <= 1 for n in n_objects) else 'split'
+        return 'f16' if not self._auto_peaked and all(int(n) <= 1 for n in n_objects) else 'split'
 
     @torch.no_grad()
     def frame_step(self, ctx, bank, prev_frame, prev_mask, cur_frame, cur_flow, commit):
@@ -458,6 +467,7 @@ class RMNet(nn.Module):
             out = self.forward(frames, masks, optical_flows, n_objects, memorize_every, device=dev, graph=graph,
                                return_logits=return_logits, _precision='split')
             self.last_clip['reread'] = 'split: largest logit %.1f > %.1f' % (logit_max, AUTO_LOGIT_BOUND)
+            self._auto_peaked = True        # (sticky: this network's later one-object clips start in 'split')
             return out
         return (est, logits) if return_logits else est
 

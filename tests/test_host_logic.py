@@ -386,3 +386,24 @@ def test_bench_becomes_its_own_launcher_for_several_gpus(monkeypatch):
     assert cmd[i + 1:] == ['--gpus', '4', '--steps', '3', '--warmup', '1']
     assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
     assert bench.DEFAULT_CLIPS == 16
+
+
+def test_auto_read_precision_start_is_sticky_per_network():
+    """``read_precision='auto'`` (rmnet_amd/rmnet.py): one-object clips start in 'f16', clips with several objects in 'split'; once a
+    one-object clip of this network measured logits beyond AUTO_LOGIT_BOUND (the flag ``forward`` sets after the re-read) its later
+    one-object clips start in 'split' -- no clip is processed twice again -- until new reference weights are loaded / the rule is
+    reset.  A forced arithmetic ignores the flag.  (The measured half of the rule runs on the GPU: test_key_temperature_sweep.)"""
+    from rmnet_amd.rmnet import RMNet
+    net = RMNet(None)
+    assert net.resolve_read_precision([1]) == 'f16' and net.resolve_read_precision([1, 1]) == 'f16'
+    assert net.resolve_read_precision([1, 3]) == 'split'
+    net._auto_peaked = True                       # what forward() leaves behind after re-reading a peaked clip in 'split'
+    assert net.resolve_read_precision([1]) == 'split' and net.resolve_read_precision([3]) == 'split'
+    net.reset_auto_precision()
+    assert net.resolve_read_precision([1]) == 'f16'
+    net._auto_peaked = True
+    net.load_reference_state_dict({'module.' + k: v for k, v in net.state_dict().items()})      # new weights: a new logit scale
+    assert net.resolve_read_precision([1]) == 'f16'
+    forced = RMNet(None, read_precision='f16')
+    forced._auto_peaked = True
+    assert forced.resolve_read_precision([1]) == 'f16' and forced.resolve_read_precision([5]) == 'f16'
