@@ -2094,6 +2094,30 @@ def test_key_temperature_sweep(mode, scale, oracle_mod):
         assert iou >= 0.999, (mode, iou)
 
 
+def test_auto_rule_is_sticky_across_clips_of_one_network():
+    """'auto' on a network whose soft-max is peaked (keys x 4): the FIRST one-object clip starts in 'f16', measures logits beyond
+    rmnet.AUTO_LOGIT_BOUND and is re-read in 'split'; the SECOND clip of the same network starts in 'split' -- it is not processed twice
+    -- and gives the masks of the first clip's re-read; ``reset_auto_precision()`` returns to the optimistic start."""
+    from rmnet_amd import networks, rmnet as rmnet_mod
+    from rmnet_amd.rmnet import RMNet
+    name, scale = 'live240', 4.0
+    prod = networks.procedural_init_(RMNet(None)).to(dev()).eval()
+    lf.shift_foreground_bias(lf.scale_keys(prod, scale), lf.TEMPERATURE_POINTS[name][scale])
+    prod.fuse_epilogues()
+    frames, masks, flows, n_objects, every, _ = lf.make_clip(name)
+    with torch.no_grad():
+        first = prod(frames, masks, flows, n_objects, every).cpu()
+        info1 = dict(prod.last_clip)
+        second = prod(frames, masks, flows, n_objects, every).cpu()
+        info2 = dict(prod.last_clip)
+    assert info1['reread'] is not None and info1['reread'].startswith('split') and info1['logit_max'] > rmnet_mod.AUTO_LOGIT_BOUND, info1
+    assert info2['read_precision'] == 'split' and info2['reread'] is None, info2
+    assert prod.resolve_read_precision([1]) == 'split'
+    assert float((first - second).abs().max()) < 1e-4          # two 'split' runs of the same clip
+    prod.reset_auto_precision()
+    assert prod.resolve_read_precision([1]) == 'f16'
+
+
 @pytest.mark.parametrize('clip,mutation', [('live480-b', 'zero'), ('live480-b', 'noise-1pct'), ('3obj-480p', 'noise-1pct')])
 def test_mutated_memory_read_fails_the_parity_metric(clip, mutation, oracle_mod, monkeypatch):
     """Mutation check of the parity metric: the SAME comparison as the parity tests (GPU loop vs CPU path, label IoU >= 0.999
