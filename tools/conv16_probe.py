@@ -38,16 +38,44 @@ def fp32_boundaries(net, tfn=None):
     return net, tfn
 
 
+def _to_f32(x):
+    if torch.is_tensor(x):
+        return x.float() if x.is_floating_point() else x
+    if isinstance(x, (tuple, list)):
+        return type(x)(_to_f32(t) for t in x)
+    return x
+
+
+PARTS = {'enc': ('encoder_memory', 'encoder_query'), 'kv': ('kv_memory', 'kv_query'), 'dec': ('decoder',)}
+
+
+def autocast_parts(net, parts, dtype):
+    """Only the named stacks of ``net`` run under autocast (their outputs leave as fp32): which stack pays how much of the IoU."""
+    for part in parts:
+        for name in PARTS[part]:
+            mod = getattr(net, name)
+            inner = mod.forward
+
+            def wrapped(*a, _f=inner):
+                with torch.autocast('cuda', dtype=dtype):
+                    return _to_f32(_f(*a))
+            mod.forward = wrapped
+    return net
+
+
 def cast_ctx(dtype):
     return contextlib.nullcontext() if dtype is None else torch.autocast('cuda', dtype=dtype)
 
 
-def loop_fps(dtype, dev, clips, steps, warmup):
+def loop_fps(dtype, dev, clips, steps, warmup, parts=None):
     net = networks.procedural_init_(RMNet(None, read_precision='auto')).to(dev).eval()
     tfn = networks.procedural_init_(TinyFlowNet(None)).to(dev).eval()
     net = net.to(memory_format=torch.channels_last)
     tfn = tfn.to(memory_format=torch.channels_last)
     fp32_boundaries(net, tfn)
+    if parts:
+        autocast_parts(net, parts, dtype)
+        dtype = None
     n_clip = 12
     cl = [synthetic_clip(n_clip, K_CH, H, W, seed=c, size=2.1) for c in range(clips)]
     frames = torch.cat([c[0] for c in cl]).to(dev)
@@ -76,7 +104,7 @@ def loop_fps(dtype, dev, clips, steps, warmup):
     return clips * steps / dt, 1e3 * dt / steps, bank.logit_max()
 
 
-def fixture_rows(name, dev, with_cpu):
+def fixture_rows(name, dev, with_cpu, selective=()):
     frames, masks, flows, n_objects, every, delta = lf.make_clip(name)
     rows, ref_gpu = {}, None
     cpu = None
@@ -91,11 +119,16 @@ def fixture_rows(name, dev, with_cpu):
         torch.set_num_threads(nt)
         rows['cpu_path_s'] = round(time.time() - t0, 1)
         lf.assert_live(cpu[0], name)
-    for tag, dtype in (('fp32', None), ('fp16', torch.float16), ('bf16', torch.bfloat16)):
+    cases = [('fp32', None, None)] + ([('fp16', torch.float16, None), ('bf16', torch.bfloat16, None)] if not selective else
+                                     [('fp16:' + '+'.join(ps), torch.float16, ps) for ps in selective])
+    for tag, dtype, parts in cases:
         net = networks.procedural_init_(RMNet(None, read_precision='auto')).to(dev).eval()
         lf.shift_foreground_bias(net, delta)
         net = net.to(memory_format=torch.channels_last)
         fp32_boundaries(net)
+        if parts:
+            autocast_parts(net, parts, dtype)
+            dtype = None
         with cast_ctx(dtype):
             est, logits = net(frames, masks, flows, n_objects, every, return_logits=True)
         est, logits = est.float().cpu(), logits.float().cpu()
@@ -118,6 +151,7 @@ def main():
     ap.add_argument('--clips', type=int, default=16)
     ap.add_argument('--fixture', default='live480-a')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--selective', default='', help="fp16 for some stacks only, e.g. 'enc,dec,enc+kv' (enc = both ResNet-50 encoders, kv = the KeyValue heads, dec = the decoder)")
     ap.add_argument('--out', default='')
     args = ap.parse_args()
     assert torch.cuda.is_available(), 'needs the GPU box'
@@ -126,9 +160,12 @@ def main():
     res = {'workload': '480x854, 1 object, T = 5 pinned, %d clips per GPU, channels_last, module graph (no fused glue), %d steps' % (args.clips, args.steps),
            'loop': {}, 'fixture': {}}
     torch.backends.cudnn.benchmark = True          # MIOpen find, as bench.py
-    for tag, dtype in (('fp32', None), ('fp16', torch.float16), ('bf16', torch.bfloat16)):
+    selective = [tuple(c.split('+')) for c in args.selective.split(',') if c]
+    loops = [('fp32', None, None), ('fp16', torch.float16, None), ('bf16', torch.bfloat16, None)] if not selective else \
+        [('fp16:' + '+'.join(ps), torch.float16, ps) for ps in selective]
+    for tag, dtype, parts in loops:
         try:
-            fps, ms, lmax = loop_fps(dtype, dev, args.clips, args.steps, args.warmup)
+            fps, ms, lmax = loop_fps(dtype, dev, args.clips, args.steps, args.warmup, parts)
             res['loop'][tag] = {'frames_per_s': round(fps, 1), 'ms_per_step': round(ms, 2), 'largest_logit': round(lmax, 2)}
         except Exception as exc:      # (a dtype MIOpen cannot serve on this build is a finding, not a crash)
             res['loop'][tag] = {'error': repr(exc)[:300]}
@@ -136,7 +173,7 @@ def main():
         torch.cuda.empty_cache()
     torch.backends.cudnn.benchmark = False         # (batch-1 fixture shapes: no second find per dtype)
     try:
-        res['fixture'][args.fixture] = fixture_rows(args.fixture, dev, not args.no_cpu)
+        res['fixture'][args.fixture] = fixture_rows(args.fixture, dev, not args.no_cpu, selective)
     except Exception as exc:
         res['fixture'][args.fixture] = {'error': repr(exc)[:300]}
     line = json.dumps(res)
