@@ -151,6 +151,7 @@ def main():
     ap.add_argument('--clips', type=int, default=16)
     ap.add_argument('--fixture', default='live480-a')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-loop', action='store_true', help='fixtures only')
     ap.add_argument('--selective', default='', help="fp16 for some stacks only, e.g. 'enc,dec,enc+kv' (enc = both ResNet-50 encoders, kv = the KeyValue heads, dec = the decoder)")
     ap.add_argument('--out', default='')
     args = ap.parse_args()
@@ -163,7 +164,7 @@ def main():
     selective = [tuple(c.split('+')) for c in args.selective.split(',') if c]
     loops = [('fp32', None, None), ('fp16', torch.float16, None), ('bf16', torch.bfloat16, None)] if not selective else \
         [('fp16:' + '+'.join(ps), torch.float16, ps) for ps in selective]
-    for tag, dtype, parts in loops:
+    for tag, dtype, parts in ([] if args.no_loop else loops):
         try:
             fps, ms, lmax = loop_fps(dtype, dev, args.clips, args.steps, args.warmup, parts)
             res['loop'][tag] = {'frames_per_s': round(fps, 1), 'ms_per_step': round(ms, 2), 'largest_logit': round(lmax, 2)}
@@ -172,10 +173,11 @@ def main():
         print('loop', tag, json.dumps(res['loop'][tag]), flush=True)
         torch.cuda.empty_cache()
     torch.backends.cudnn.benchmark = False         # (batch-1 fixture shapes: no second find per dtype)
-    try:
-        res['fixture'][args.fixture] = fixture_rows(args.fixture, dev, not args.no_cpu, selective)
-    except Exception as exc:
-        res['fixture'][args.fixture] = {'error': repr(exc)[:300]}
+    for fx in args.fixture.split(','):
+        try:
+            res['fixture'][fx] = fixture_rows(fx, dev, not args.no_cpu, selective)
+        except Exception as exc:
+            res['fixture'][fx] = {'error': repr(exc)[:300]}
     line = json.dumps(res)
     print(line)
     if args.out:
