@@ -895,7 +895,9 @@ def main():
                        'hip_graph': bool(args.graph), 'clips_per_gpu': B,
                        'batchnorm_folded': bool(args.fold_bn),
                        'fused_epilogues': bool(not args.fold_bn and not args.no_fuse_epilogue)},
-            'roofline': {'bound': 'mfma',
+            'roofline': {'bound': 'hbm',        # the roof achieved / peak / frac are quoted against (BASELINE.json's metric: HBM GB/s vs peak)
+                         'limited_by': 'not HBM: matrix pipe, L1 / TA and LDS of a CU at ~50 % each inside the tile walk (DESIGN.md section 4; '
+                                       'the mfma object below prices the same launch against the fp16 MFMA peak)',
                          'kernel': 'bk_main<%d> = the whole regional memory read in ONE launch (%s MFMA read of the bank, merge of the '
                                    'partial results by the last workgroup of every query tile, masked cells, q_val half of the cat)'
                                    % (n_terms, {3: 'split-fp16 (3-term)', 2: 'fp16-operand, exact-query (2 + 1 terms)', 1: 'fp16-operand (1-term)'}[n_terms]),
