@@ -152,6 +152,8 @@ def main():
     ap.add_argument('--fixture', default='live480-a')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-loop', action='store_true', help='fixtures only')
+    ap.add_argument('--no-fixture', action='store_true', help='loops only')
+    ap.add_argument('--dtypes', default='fp32,fp16,bf16', help='loop dtypes of the all-stacks run')
     ap.add_argument('--selective', default='', help="fp16 for some stacks only, e.g. 'enc,dec,enc+kv' (enc = both ResNet-50 encoders, kv = the KeyValue heads, dec = the decoder)")
     ap.add_argument('--out', default='')
     args = ap.parse_args()
@@ -162,7 +164,7 @@ def main():
            'loop': {}, 'fixture': {}}
     torch.backends.cudnn.benchmark = True          # MIOpen find, as bench.py
     selective = [tuple(c.split('+')) for c in args.selective.split(',') if c]
-    loops = [('fp32', None, None), ('fp16', torch.float16, None), ('bf16', torch.bfloat16, None)] if not selective else \
+    loops = [l for l in (('fp32', None, None), ('fp16', torch.float16, None), ('bf16', torch.bfloat16, None)) if l[0] in args.dtypes.split(',')] if not selective else \
         [('fp16:' + '+'.join(ps), torch.float16, ps) for ps in selective]
     for tag, dtype, parts in ([] if args.no_loop else loops):
         try:
@@ -173,7 +175,7 @@ def main():
         print('loop', tag, json.dumps(res['loop'][tag]), flush=True)
         torch.cuda.empty_cache()
     torch.backends.cudnn.benchmark = False         # (batch-1 fixture shapes: no second find per dtype)
-    for fx in args.fixture.split(','):
+    for fx in ([] if args.no_fixture else args.fixture.split(',')):
         try:
             res['fixture'][fx] = fixture_rows(fx, dev, not args.no_cpu, selective)
         except Exception as exc:
