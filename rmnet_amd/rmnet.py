@@ -352,7 +352,7 @@ class RMNet(nn.Module):
         logits turn out large is re-read in 'split' at the end of ``forward``, and one-object clips start in 'split' from then on)."""
         if self.read_precision != 'auto':
             return self.read_precision
-        return 'f16' if not self._auto_peaked and all(int(n) <= 1 for n in n_objects) else 'split'
+        return 'f16' if not getattr(self, '_auto_peaked', False) and all(int(n) <= 1 for n in n_objects) else 'split'
 
     @torch.no_grad()
     def frame_step(self, ctx, bank, prev_frame, prev_mask, cur_frame, cur_flow, commit):
