@@ -13,8 +13,12 @@
 //   5. the plan's search for C ends with no more chunks than workgroups, with and without "own column blocks", and with the
 //      EQUALISED blocks (no remainder chunks; block lengths differ by at most one tile and never exceed C);
 //   6. [r6] a launch with more pairs than workgroups runs in ROUNDS: whole objects first (one column block each), the objects behind them cut
-//      into equal blocks that fill one more round; no remainder chunks, slots only for the cut objects, at most R + 2 rounds.
+//      into equal blocks that fill one more round; no remainder chunks, slots only for the cut objects, at most R + 2 rounds;
+//   7. plan_div's DEVICE branch (an fp32 reciprocal, off by at most one, fixed up by the remainder) restated with the reciprocal one ulp
+//      low / correctly rounded / one ulp high (v_rcp_f32 is accurate to one ulp): exact for every operand pair below its documented 2^22
+//      (round-5 advisor: only the host branch x / c was under test).
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -207,6 +211,41 @@ void check_launch(const std::vector<int>& nqt, const std::vector<int>& njt, int 
 
 }  // namespace
 
+
+// common.h, plan_div(), the __HIP_DEVICE_COMPILE__ branch, with v_rcp_f32 modelled as the correctly rounded reciprocal moved by `ulp` ulps
+int plan_div_device(int x, int c, int ulp) {
+  float rc = 1.0f / (float)c;
+  for (int i = 0; i < ulp; ++i) rc = std::nextafterf(rc, 2.0f);
+  for (int i = 0; i > ulp; --i) rc = std::nextafterf(rc, 0.0f);
+  int q = (int)((float)x * rc);
+  const int r = x - q * c;
+  return q + (r >= c ? 1 : 0) - (r < 0 ? 1 : 0);
+}
+
+void check_plan_div_device() {
+  auto one = [&](int x, int c) {
+    for (int ulp = -1; ulp <= 1; ++ulp)
+      if (plan_div_device(x, c, ulp) != x / c) {
+        if (fails < 20) std::printf("plan_div device branch: %d / %d with the reciprocal %+d ulp -> %d, exact %d\n", x, c, ulp, plan_div_device(x, c, ulp), x / c);
+        ++fails;
+      }
+  };
+  const int top = (1 << 22) - 1;
+  for (int c = 1; c <= 2048; ++c)                       // every divisor the plan can see (chunk lengths, query tiles, workgroups) ...
+    for (int k = 0; k <= 64; ++k) {                     // ... against numerators around its multiples, small and at the contract's edge
+      for (int d = -2; d <= 2; ++d) {
+        const long long lo = (long long)k * c + d, hi = (long long)(top / c - k) * c + d;
+        if (lo >= 0 && lo <= top) one((int)lo, c);
+        if (hi >= 0 && hi <= top) one((int)hi, c);
+      }
+    }
+  std::mt19937 rng(99);
+  for (int i = 0; i < 4000000; ++i) {
+    const int c = 1 + (int)(rng() % (i & 1 ? top : 4096)), x = (int)(rng() % (unsigned)(top + 1));
+    one(x, c);
+  }
+}
+
 int main() {
   // 1. bank_chunks on a dense sweep of single objects (both segment costs, with and without own blocks)
   for (int sc : {kSegCost, kSegCostF16})
@@ -234,6 +273,7 @@ int main() {
       check_launch(l.first, l.second, t, kSegCost, 1);
       check_launch(l.first, l.second, t, kSegCostF16, 2);
     }
+  check_plan_div_device();
   if (fails) { std::printf("plan_check: %d failures\n", fails); return 1; }
   std::printf("plan_check ok: %zu launches x %zu targets x 2 modes\n", launches.size(), sizeof(targets) / sizeof(targets[0]));
   return 0;
