@@ -308,3 +308,46 @@ def test_live_fixture_sees_mutations_and_prices_the_roundings(oracle_mod):
         assert lf.label_iou(est, ref) >= 0.9995, mode
         assert gaps[mode] < 5e-3, (mode, gaps[mode])
     assert gaps['qx'] < gaps['f16'] and gaps['mixed'] < gaps['f16']     # q's rounding is the largest single contribution
+
+
+def test_auto_logit_bound_separates_the_key_temperature_points(oracle_mod):
+    """The calibration behind ``read_precision='auto'`` (rmnet_amd/rmnet.py: AUTO_LOGIT_BOUND; profiles/r06_iou_temperature.md), on the CPU
+    at 240x432: with the key convolutions of both KeyValue heads scaled by s (every affinity logit by s^2) the fp16-operand arithmetic --
+    restated on the CPU path (live_fixture.rounded_reader) -- is at 0.9999 of the unrounded path's masks at s = 1 and BELOW 0.9995 at
+    s = 4, and the largest logit of the clip, the quantity the bank measures, is under the bound at s = 1 (4.5), above it at s = 2 (18: the
+    kernel's reference is deferred by up to 8, so the rule MAY still keep 'f16' there -- where it is at 0.9994, inside the task's 1e-3) and
+    beyond it by more than the deferral at s = 4 (73): the rule drops 'f16' before the sweep says it must."""
+    import live_fixture as lf
+    from rmnet_amd import networks
+    from rmnet_amd.rmnet import AUTO_LOGIT_BOUND
+    name = 'live240'
+    frames, masks, flows, n_objects, every, _ = lf.make_clip(name)
+
+    class MaxLogit:          # MemoryReader.forward (models/rmnet.py:147-165) that keeps the largest affinity logit
+        smax = 0.0
+
+        def __call__(self, m_key, m_val, q_key, q_val):
+            no, De, T, h, w = m_key.shape
+            S = torch.bmm(m_key.reshape(no, De, -1).transpose(1, 2), q_key.reshape(no, De, -1)) / (De ** 0.5)
+            self.smax = max(self.smax, float(S.max()))
+            mem = torch.bmm(m_val.reshape(no, -1, T * h * w), torch.softmax(S, dim=1)).reshape(no, -1, h, w)
+            return torch.cat([mem, q_val], dim=1), None
+
+    def run(reader, s):
+        net = networks.procedural_init_(oracle_mod.OracleRMNet(reader=reader)).eval()
+        lf.shift_foreground_bias(lf.scale_keys(net, s), lf.TEMPERATURE_POINTS[name][s])
+        with torch.no_grad():
+            return net(frames, masks, flows, n_objects, every)
+
+    iou, smax = {}, {}
+    for s in (1.0, 2.0, 4.0):
+        stat = MaxLogit()
+        ref = run(stat, s)
+        smax[s] = stat.smax
+        lf.assert_live(ref, '%s s=%g' % (name, s))
+        iou[s] = lf.label_iou(run(lf.rounded_reader('f16'), s), ref)
+    assert smax[1.0] <= AUTO_LOGIT_BOUND < smax[2.0] and smax[4.0] > AUTO_LOGIT_BOUND + 8.0, smax
+    assert iou[1.0] >= 0.9998, iou
+    assert iou[2.0] >= 0.999, iou
+    assert iou[4.0] < 0.9995, iou
+    print('largest logit', smax, 'emulated f16 IoU', iou)
